@@ -1,0 +1,275 @@
+// api.hip -- extern "C" entry points of include/ed3dgs.h for the rasterizer (host orchestration).
+// Stage order and the single blocking read-back follow CudaRasterizer::Rasterizer::forward / backward
+// (CR/rasterizer_impl.cu:255-432, 436-578); everything is enqueued on the caller's stream (the reference uses the
+// legacy null stream throughout).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "common.h"
+
+namespace ed3 {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+bool check_hip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    set_error(std::string("[HIP ERROR] ") + what + ": " + hipGetErrorString(e));
+    return false;
+}
+
+GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
+{
+    GeometryState g;
+    obtain(chunk, g.rec, P * REC, 128);
+    obtain(chunk, g.rec_coord, P * RECC, 128);
+    obtain(chunk, g.depths, P, 128);
+    obtain(chunk, g.cov3D, P * 6, 128);
+    obtain(chunk, g.clamped, P, 128);
+    obtain(chunk, g.tiles_touched, P, 128);
+    g.scan_size = scan_temp_bytes((int)P);
+    obtain(chunk, g.scan_space, g.scan_size, 128);
+    obtain(chunk, g.point_offsets, P, 128);
+    return g;
+}
+ImageState ImageState::from_chunk(char *&chunk, size_t N, size_t T)
+{
+    ImageState img;
+    obtain(chunk, img.n_contrib, N * 2, 128);
+    obtain(chunk, img.ranges, T * 2, 128);
+    obtain(chunk, img.accum_coord, N * 3, 128);
+    obtain(chunk, img.accum_depth, N, 128);
+    obtain(chunk, img.normal_length, N, 128);
+    return img;
+}
+BinningState BinningState::from_chunk(char *&chunk, size_t R)
+{
+    BinningState b;
+    obtain(chunk, b.point_list, R, 128);
+    obtain(chunk, b.point_list_unsorted, R, 128);
+    obtain(chunk, b.keys, R, 128);
+    obtain(chunk, b.keys_unsorted, R, 128);
+    b.sort_size = sort_temp_bytes((int)R);
+    obtain(chunk, b.sort_space, b.sort_size, 128);
+    return b;
+}
+
+// CR/rasterizer_impl.cu:35-50
+static uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) { step /= 2; if (n >> msb) msb += step; else msb -= step; }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+static inline size_t tiles_of(int W, int H) { return (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+
+struct StageCheck {
+    bool debug; hipStream_t s;
+    bool operator()(const char *what) const
+    {
+        if (!check_hip(hipGetLastError(), what)) return false;
+        if (debug && !check_hip(hipStreamSynchronize(s), what)) return false;  // CR/auxiliary.h:404-411
+        return true;
+    }
+};
+
+}  // namespace ed3
+
+using namespace ed3;
+
+extern "C" {
+
+const char *ed3dgs_last_error(void) { return g_error.c_str(); }
+int ed3dgs_abi_version(void) { return 1; }
+
+size_t ed3dgs_geometry_bytes(int P)
+{
+    char *p = nullptr;
+    GeometryState::from_chunk(p, (size_t)(P > 0 ? P : 0));
+    return (size_t)p + 128;
+}
+size_t ed3dgs_image_bytes(int width, int height)
+{
+    char *p = nullptr;
+    ImageState::from_chunk(p, (size_t)width * height, tiles_of(width, height));
+    return (size_t)p + 128;
+}
+size_t ed3dgs_binning_bytes(int R)
+{
+    char *p = nullptr;
+    BinningState::from_chunk(p, (size_t)(R > 0 ? R : 0));
+    return (size_t)p + 128;
+}
+size_t ed3dgs_backward_workspace_bytes(int P, int require_coord)
+{
+    return (size_t)(P > 0 ? P : 0) * GREC * sizeof(float) * (require_coord ? 2 : 1) + 256;
+}
+
+int ed3dgs_rasterize_forward(
+    ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_alloc_fn binning_alloc, void *binning_user,
+    ed3dgs_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
+    int height, const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+    const float *tongue_class, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+    float tan_fovy, float kernel_size, int prefiltered, float *out_color, float *out_coord, float *out_mcoord,
+    float *out_depth, float *out_mdepth, float *out_alpha, float *out_tongue, float *out_normal, int *radii,
+    int require_coord, int require_depth, int debug, void *stream)
+{
+    (void)prefiltered;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) { set_error("ed3dgs_rasterize_forward: bad P/width/height"); return ED3DGS_ERR_INVALID; }
+    if (!geometry_alloc || !binning_alloc || !image_alloc) { set_error("ed3dgs_rasterize_forward: null allocator"); return ED3DGS_ERR_INVALID; }
+    if (P == 0) return 0;  // DGR/rasterize_points.cu:92
+    if (!means3D || !opacities || !tongue_class || !viewmatrix || !projmatrix || !cam_pos || !background || !radii ||
+        !out_color || !out_alpha || !out_tongue) {
+        set_error("ed3dgs_rasterize_forward: null required pointer"); return ED3DGS_ERR_INVALID;
+    }
+    if (!colors_precomp && !shs) {  // CR/rasterizer_impl.cu:311-314
+        set_error("For non-RGB, provide precomputed Gaussian colors!"); return ED3DGS_ERR_INVALID;
+    }
+    if (!cov3D_precomp && (!scales || !rotations)) { set_error("ed3dgs_rasterize_forward: need scales+rotations or cov3D_precomp"); return ED3DGS_ERR_INVALID; }
+    if (shs && !colors_precomp && (M < (D + 1) * (D + 1) || D < 0 || D > 3)) { set_error("ed3dgs_rasterize_forward: SH degree/coeff mismatch"); return ED3DGS_ERR_INVALID; }
+    if ((require_coord && (!out_coord || !out_mcoord)) || (require_depth && (!out_depth || !out_mdepth)) ||
+        ((require_coord || require_depth) && !out_normal)) {
+        set_error("ed3dgs_rasterize_forward: null output plane for requested variant"); return ED3DGS_ERR_INVALID;
+    }
+    StageCheck ok{debug != 0, s};
+
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    char *chunk = geometry_alloc(geometry_user, ed3dgs_geometry_bytes(P));
+    if (!chunk) { set_error("geometry allocation failed"); return ED3DGS_ERR_ALLOC; }
+    GeometryState geom = GeometryState::from_chunk(chunk, P);
+    char *img_chunk = image_alloc(image_user, ed3dgs_image_bytes(width, height));
+    if (!img_chunk) { set_error("image allocation failed"); return ED3DGS_ERR_ALLOC; }
+    const size_t T = tiles_of(width, height);
+    ImageState img = ImageState::from_chunk(img_chunk, (size_t)width * height, T);
+
+    launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
+                      colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
+                      focal_y, kernel_size, radii, geom, s);
+    if (!ok("preprocess")) return ED3DGS_ERR_HIP;
+    if (!run_scan(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.point_offsets, P, s)) return ED3DGS_ERR_HIP;
+    if (!ok("scan")) return ED3DGS_ERR_HIP;
+
+    // the one blocking read-back of the path (CR/rasterizer_impl.cu:359)
+    uint32_t num_rendered_u = 0;
+    if (!check_hip(hipMemcpyAsync(&num_rendered_u, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipStreamSynchronize(s), "sync num_rendered")) return ED3DGS_ERR_HIP;
+    if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
+    const int R = (int)num_rendered_u;
+
+    char *bin_chunk = binning_alloc(binning_user, ed3dgs_binning_bytes(R));
+    if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
+    BinningState bin = BinningState::from_chunk(bin_chunk, R);
+
+    launch_duplicate_with_keys(P, geom, radii, width, height, bin.keys_unsorted, bin.point_list_unsorted, s);
+    if (!ok("duplicateWithKeys")) return ED3DGS_ERR_HIP;
+    const int bit = (int)higher_msb((uint32_t)T);
+    if (!run_sort(bin.sort_space, bin.sort_size, bin.keys_unsorted, bin.keys, bin.point_list_unsorted, bin.point_list, R, 32 + bit, s)) return ED3DGS_ERR_HIP;
+    if (!ok("sort")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
+    launch_identify_tile_ranges(R, bin.keys, img.ranges, s);
+    if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
+
+    launch_render_forward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
+                          background, require_coord != 0, require_depth != 0, out_color, out_coord, out_mcoord,
+                          out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img, s);
+    if (!ok("render")) return ED3DGS_ERR_HIP;
+    return R;
+}
+
+int ed3dgs_rasterize_backward(
+    int P, int D, int M, int R, const float *background, int width, int height, const float *means3D, const float *shs,
+    const float *colors_precomp, const float *alphas, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+    float tan_fovy, float kernel_size, const int *radii, const float *normalmap, char *geometry_buffer,
+    char *binning_buffer, char *image_buffer, const float *dL_dpix, const float *dL_dpix_coord,
+    const float *dL_dpix_mcoord, const float *dL_dpix_depth, const float *dL_dpix_mdepth, const float *dL_dalphas,
+    const float *dL_dpix_normal, float *dL_dmean2D, float *dL_dcolor, float *dL_dopacity, float *dL_dmean3D,
+    float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot, char *workspace, size_t workspace_bytes,
+    int require_coord, int require_depth, int q1_reference, int debug, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0 || R < 0) { set_error("ed3dgs_rasterize_backward: bad sizes"); return ED3DGS_ERR_INVALID; }
+    if (P == 0) return 0;  // DGR/rasterize_points.cu:199
+    if (!geometry_buffer || !binning_buffer || !image_buffer || !workspace) { set_error("ed3dgs_rasterize_backward: null state buffer"); return ED3DGS_ERR_INVALID; }
+    if (workspace_bytes < ed3dgs_backward_workspace_bytes(P, require_coord)) { set_error("ed3dgs_rasterize_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
+    if (!dL_dpix || !dL_dalphas || !alphas || !radii || !dL_dmean2D || !dL_dcolor || !dL_dopacity || !dL_dmean3D || !dL_dcov3D) {
+        set_error("ed3dgs_rasterize_backward: null required pointer"); return ED3DGS_ERR_INVALID;
+    }
+    if ((require_coord && (!dL_dpix_coord || !dL_dpix_mcoord)) || (require_depth && (!dL_dpix_depth || !dL_dpix_mdepth)) ||
+        ((require_coord || require_depth) && (!dL_dpix_normal || !normalmap))) {
+        set_error("ed3dgs_rasterize_backward: null upstream gradient for requested variant"); return ED3DGS_ERR_INVALID;
+    }
+    if (shs && !colors_precomp && !dL_dsh) { set_error("ed3dgs_rasterize_backward: dL_dsh is null"); return ED3DGS_ERR_INVALID; }
+    if (scales && (!rotations || !dL_dscale || !dL_drot)) { set_error("ed3dgs_rasterize_backward: scale/rot outputs null"); return ED3DGS_ERR_INVALID; }
+    StageCheck ok{debug != 0, s};
+
+    char *gc = geometry_buffer, *bc = binning_buffer, *ic = image_buffer;
+    GeometryState geom = GeometryState::from_chunk(gc, P);
+    BinningState bin = BinningState::from_chunk(bc, R);
+    ImageState img = ImageState::from_chunk(ic, (size_t)width * height, tiles_of(width, height));
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    char *wc = workspace;
+    float *grec = nullptr, *grec_coord = nullptr;
+    obtain(wc, grec, (size_t)P * GREC, 128);
+    if (require_coord) obtain(wc, grec_coord, (size_t)P * GREC, 128);
+    const size_t zero_bytes = (size_t)P * GREC * sizeof(float) * (require_coord ? 2 : 1);
+    if (!check_hip(hipMemsetAsync(grec, 0, zero_bytes, s), "memset gradient records")) return ED3DGS_ERR_HIP;
+
+    if (R > 0) {
+        launch_render_backward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
+                               background, require_coord != 0, require_depth != 0, alphas, normalmap, img, dL_dpix,
+                               dL_dpix_coord, dL_dpix_mcoord, dL_dpix_depth, dL_dpix_mdepth, dL_dalphas,
+                               dL_dpix_normal, grec, grec_coord, s);
+        if (!ok("render backward")) return ED3DGS_ERR_HIP;
+    }
+    launch_preprocess_backward(P, D, M, means3D, radii, shs, scales, rotations, scale_modifier, cov3D_precomp,
+                               viewmatrix, projmatrix, cam_pos, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, geom,
+                               grec, grec_coord, colors_precomp != nullptr, q1_reference != 0, width, height,
+                               dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s);
+    if (!ok("preprocess backward")) return ED3DGS_ERR_HIP;
+    return 0;
+}
+
+int ed3dgs_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
+                        void *stream)
+{
+    (void)projmatrix;
+    if (P < 0) { set_error("ed3dgs_mark_visible: bad P"); return ED3DGS_ERR_INVALID; }
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) { set_error("ed3dgs_mark_visible: null pointer"); return ED3DGS_ERR_INVALID; }
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    if (!check_hip(hipGetLastError(), "mark_visible")) return ED3DGS_ERR_HIP;
+    return 0;
+}
+
+int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geometry_buffer, const char *binning_buffer,
+                          const char *image_buffer, ed3dgs_state_view *out)
+{
+    if (!out || !geometry_buffer || !image_buffer) { set_error("ed3dgs_state_view_get: null pointer"); return ED3DGS_ERR_INVALID; }
+    std::memset(out, 0, sizeof(*out));
+    char *gc = const_cast<char *>(geometry_buffer), *ic = const_cast<char *>(image_buffer);
+    GeometryState g = GeometryState::from_chunk(gc, P);
+    ImageState img = ImageState::from_chunk(ic, (size_t)width * height, tiles_of(width, height));
+    out->rec = g.rec; out->rec_coord = g.rec_coord; out->depths = g.depths; out->cov3D = g.cov3D;
+    out->clamped = g.clamped; out->tiles_touched = g.tiles_touched; out->point_offsets = g.point_offsets;
+    out->ranges = img.ranges; out->n_contrib = img.n_contrib; out->accum_coord = img.accum_coord;
+    out->accum_depth = img.accum_depth; out->normal_length = img.normal_length;
+    if (binning_buffer) {
+        char *bc = const_cast<char *>(binning_buffer);
+        BinningState b = BinningState::from_chunk(bc, R);
+        out->point_list_keys = b.keys; out->point_list = b.point_list;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// common.h -- shared declarations of the gfx950 HIP kernels behind include/ed3dgs.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/ed3dgs.h"
+
+namespace ed3 {
+
+constexpr int TILE = 16;        // CR/config.h:16-17
+constexpr int REC = 16;         // floats per per-Gaussian raster record (64 B)
+constexpr int RECC = 12;        // floats per coord record (48 B)
+constexpr int GREC = 16;        // floats per per-Gaussian gradient record
+constexpr float NORMALIZE_EPS = 1.0E-12F;  // CR/auxiliary.h:23
+
+// record slots
+enum { R_X = 0, R_Y, R_CX, R_CY, R_CZ, R_W, R_R, R_G, R_B, R_TG, R_TS, R_RPX, R_RPY, R_NX, R_NY, R_NZ };
+// gradient record slots (tile backward -> per-Gaussian backward)
+enum { G_R = 0, G_G, G_B, G_TS, G_RPX, G_RPY, G_NX, G_NY, G_NZ, G_MX, G_MY, G_MZ, G_CX, G_CY, G_CW, G_OP };
+// coord gradient record: view_point[3], camera_plane[6], pad
+
+void set_error(const std::string &msg);
+bool check_hip(hipError_t e, const char *what);
+
+struct GeometryState {
+    float *rec;            // [P][16]
+    float *rec_coord;      // [P][12]
+    float *depths;         // [P]
+    float *cov3D;          // [P][6]
+    uint8_t *clamped;      // [P]
+    uint32_t *tiles_touched;
+    uint32_t *point_offsets;
+    char *scan_space;
+    size_t scan_size;
+    static GeometryState from_chunk(char *&chunk, size_t P);
+};
+struct ImageState {
+    uint32_t *n_contrib;   // [2][H][W]
+    uint32_t *ranges;      // [T][2]
+    float *accum_coord;    // [3][H][W]
+    float *accum_depth;    // [H][W]
+    float *normal_length;  // [H][W]
+    static ImageState from_chunk(char *&chunk, size_t N, size_t T);
+};
+struct BinningState {
+    uint32_t *point_list;
+    uint32_t *point_list_unsorted;
+    uint64_t *keys;
+    uint64_t *keys_unsorted;
+    char *sort_space;
+    size_t sort_size;
+    static BinningState from_chunk(char *&chunk, size_t R);
+};
+
+template <typename T>
+inline void obtain(char *&chunk, T *&ptr, size_t count, size_t alignment = 128)
+{
+    size_t offset = (reinterpret_cast<uintptr_t>(chunk) + alignment - 1) & ~(alignment - 1);
+    ptr = reinterpret_cast<T *>(offset);
+    chunk = reinterpret_cast<char *>(ptr + count);
+}
+
+// ---- launchers (one per kernel file) ----
+void launch_preprocess(int P, int D, int M, const float *means, const float *scales, float scale_modifier,
+                       const float *rotations, const float *opacities, const float *tongue, const float *shs,
+                       const float *cov3D_precomp, const float *colors_precomp, const float *view, const float *proj,
+                       const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
+                       float kernel_size, int *radii, GeometryState g, hipStream_t s);
+void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s);
+void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint64_t *keys,
+                                uint32_t *values, hipStream_t s);
+void launch_identify_tile_ranges(int R, const uint64_t *keys, uint32_t *ranges, hipStream_t s);
+size_t scan_temp_bytes(int P);
+size_t sort_temp_bytes(int R);
+bool run_scan(char *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s);
+bool run_sort(char *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
+              int R, int end_bit, hipStream_t s);
+
+void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                           const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,
+                           bool depth, float *out_color, float *out_coord, float *out_mcoord, float *out_depth,
+                           float *out_mdepth, float *out_alpha, float *out_tongue, float *out_normal, ImageState img,
+                           hipStream_t s);
+void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                            const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,
+                            bool depth, const float *alphas, const float *normalmap, ImageState img,
+                            const float *dL_dpix, const float *dL_dcoord, const float *dL_dmcoord,
+                            const float *dL_ddepth, const float *dL_dmdepth, const float *dL_dalpha,
+                            const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s);
+void launch_preprocess_backward(int P, int D, int M, const float *means, const int *radii, const float *shs,
+                                const float *scales, const float *rotations, float scale_modifier,
+                                const float *cov3D_precomp, const float *view, const float *proj, const float *campos,
+                                float focal_x, float focal_y, float tan_fovx, float tan_fovy, float kernel_size,
+                                GeometryState g, const float *grec, const float *grec_coord, bool colors_precomp,
+                                bool q1_reference, int W, int H, float *dL_dmean2D, float *dL_dcolor,
+                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                float *dL_dscale, float *dL_drot, hipStream_t s);
+
+}  // namespace ed3

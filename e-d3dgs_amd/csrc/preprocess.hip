@@ -1,0 +1,305 @@
+// preprocess.hip -- K1 (per-Gaussian EWA preprocess + SH colour), K10 (frustum mark), K3 (key emission),
+// K5 (tile ranges).  Compiled with -ffp-contract=off: radii, rects, depth bits and therefore the tile lists are
+// defined by the written fp32 operand order and compared bit-exactly against the CPU oracle.
+//
+// What it computes follows CR/forward.cu:23-74 (SH), :77-264 (cov2D / planes / normal), :270-304 (cov3D),
+// :426-545 (preprocessCUDATongue), CR/auxiliary.h:57-72,155-180; how it stores differs: one 64-byte record per
+// Gaussian (everything the tile pass gathers) instead of 12 separate arrays, so the tile pass fetches whole lines.
+#include "common.h"
+#include "devmath.h"
+
+namespace ed3 {
+
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+// CR/auxiliary.h:57-60: double literals -> evaluated in fp64
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, int2 &rmin, int2 &rmax)
+{
+    rmin.x = min(gx, max(0, (int)((px - max_radius) / TILE)));
+    rmin.y = min(gy, max(0, (int)((py - max_radius) / TILE)));
+    rmax.x = min(gx, max(0, (int)((px + max_radius + TILE - 1) / TILE)));
+    rmax.y = min(gy, max(0, (int)((py + max_radius + TILE - 1) / TILE)));
+}
+
+__device__ inline v3 color_from_sh(int deg, v3 pos, v3 campos, const float *__restrict__ s, uint8_t &clamped)
+{
+    v3 dir = pos - campos;
+    dir = dir / len3(dir);
+#define SH(k) mk3(s[3 * (k)], s[3 * (k) + 1], s[3 * (k) + 2])
+    v3 result = SH(0) * SH_C0;
+    if (deg > 0) {
+        float x = dir.x, y = dir.y, z = dir.z;
+        result = result - SH(1) * (SH_C1 * y) + SH(2) * (SH_C1 * z) - SH(3) * (SH_C1 * x);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            result = result + SH(4) * (SH_C2[0] * xy) + SH(5) * (SH_C2[1] * yz) +
+                     SH(6) * (SH_C2[2] * (2.0f * zz - xx - yy)) + SH(7) * (SH_C2[3] * xz) + SH(8) * (SH_C2[4] * (xx - yy));
+            if (deg > 2) {
+                result = result + SH(9) * (SH_C3[0] * y * (3.0f * xx - yy)) + SH(10) * (SH_C3[1] * xy * z) +
+                         SH(11) * (SH_C3[2] * y * (4.0f * zz - xx - yy)) +
+                         SH(12) * (SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) +
+                         SH(13) * (SH_C3[4] * x * (4.0f * zz - xx - yy)) + SH(14) * (SH_C3[5] * z * (xx - yy)) +
+                         SH(15) * (SH_C3[6] * x * (xx - 3.0f * yy));
+            }
+        }
+    }
+#undef SH
+    result.x += 0.5f; result.y += 0.5f; result.z += 0.5f;
+    clamped = (uint8_t)((result.x < 0) | ((result.y < 0) << 1) | ((result.z < 0) << 2));
+    return mk3(fmaxf(result.x, 0.0f), fmaxf(result.y, 0.0f), fmaxf(result.z, 0.0f));
+}
+
+__device__ inline void cov3d_from_scale_rot(v3 scale, float mod, float4 rot, float cov3D[6])
+{
+    m3 S = cols3(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    S.m[0][0] = mod * scale.x; S.m[1][1] = mod * scale.y; S.m[2][2] = mod * scale.z;
+    float r = rot.x, x = rot.y, y = rot.z, z = rot.w;  // used as given (no normalisation), Q3
+    m3 R = cols3(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    m3 M = mul3(S, R);
+    m3 Sigma = mul3(tr3(M), M);
+    cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+    cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
+struct Cov2DOut { float cov[3]; float cam_plane[6]; float normal[3]; float ray_plane[2]; float coef; };
+
+__device__ inline void cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                                    float kernel_size, const float *cov3D, const float *__restrict__ view, Cov2DOut &o)
+{
+    v3 t = xform4x3(mean, view);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    txtz = t.x / t.z; tytz = t.y / t.z;
+
+    m3 J = cols3(focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z), 0.0f, focal_y / t.z,
+                 -(focal_y * t.y) / (t.z * t.z), 0, 0, 0);
+    m3 Wm = cols3(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    m3 T = mul3(Wm, J);
+    m3 Vrk = cols3(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    m3 cov = mul3(mul3(tr3(T), tr3(Vrk)), T);
+
+    o.cov[0] = cov.m[0][0] + kernel_size;
+    o.cov[1] = cov.m[0][1];
+    o.cov[2] = cov.m[1][1] + kernel_size;
+    // mip coefficient: fp64 evaluation of the clamps / ratio / sqrt, as the double literals imply (Q13)
+    const float det_0 = (float)fmax(1e-6, (double)(cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1]));
+    const float det_1 = (float)fmax(1e-6, (double)((cov.m[0][0] + kernel_size) * (cov.m[1][1] + kernel_size) -
+                                                    cov.m[0][1] * cov.m[0][1]));
+    o.coef = (float)sqrt(det_0 / (det_1 + 1e-6) + 1e-6);
+    if (det_0 <= 1e-6 || det_1 <= 1e-6) o.coef = 0.0f;
+
+    m3 evec; float eval[3];
+    int Dn = eig_sym3(Vrk, eval, evec);
+    unsigned min_id = eval[0] > eval[1] ? (eval[1] > eval[2] ? 2 : 1) : (eval[0] > eval[2] ? 2 : 0);
+    m3 Vrk_inv;
+    bool well_conditioned = eval[min_id] > 0.00000001;
+    if (well_conditioned) {
+        m3 diag = cols3(1 / eval[0], 0, 0, 0, 1 / eval[1], 0, 0, 0, 1 / eval[2]);
+        Vrk_inv = mul3(mul3(evec, diag), tr3(evec));
+    } else {
+        v3 emin = min_id == 0 ? col3(evec, 0) : (min_id == 1 ? col3(evec, 1) : col3(evec, 2));
+        Vrk_inv = outer3(emin, emin);
+    }
+    m3 cov_cam_inv = mul3(mul3(tr3(Wm), Vrk_inv), Wm);
+    v3 uvh = mk3(txtz, tytz, 1);
+    v3 uvh_m = mulv3(cov_cam_inv, uvh);
+    v3 uvh_mn = normalize3(uvh_m);
+
+    if (isnan(uvh_mn.x) || Dn == 0) {
+#pragma unroll
+        for (int ch = 0; ch < 6; ch++) o.cam_plane[ch] = 0;
+        o.normal[0] = o.normal[1] = o.normal[2] = 0;
+        o.ray_plane[0] = o.ray_plane[1] = 0;
+    } else {
+        float u2 = txtz * txtz, v2 = tytz * tytz, uv = txtz * tytz;
+        float l = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
+        m3 nJ = cols3(1 / t.z, 0.0f, -(t.x) / (t.z * t.z), 0.0f, 1 / t.z, -(t.y) / (t.z * t.z), t.x / l, t.y / l, t.z / l);
+        m3 nJ_inv = cols3(v2 + 1, -uv, 0, -uv, u2 + 1, 0, -txtz, -tytz, 0);
+        float vbn = dot3(uvh_mn, uvh);
+        float factor_normal = l / (u2 + v2 + 1);
+        v3 plane = mulv3(nJ_inv, uvh_mn / fmaxf(vbn, 0.0000001f));
+        float nl = u2 + v2 + 1;
+        o.cam_plane[0] = (-(v2 + 1) * t.z + plane.x * t.x) / nl / focal_x;
+        o.cam_plane[1] = (uv * t.z + plane.y * t.x) / nl / focal_y;
+        o.cam_plane[2] = (uv * t.z + plane.x * t.y) / nl / focal_x;
+        o.cam_plane[3] = (-(u2 + 1) * t.z + plane.y * t.y) / nl / focal_y;
+        o.cam_plane[4] = (t.x + plane.x * t.z) / nl / focal_x;
+        o.cam_plane[5] = (t.y + plane.y * t.z) / nl / focal_y;
+        o.ray_plane[0] = plane.x * l / nl / focal_x;
+        o.ray_plane[1] = plane.y * l / nl / focal_y;
+        v3 ray_normal = mk3(-plane.x * factor_normal, -plane.y * factor_normal, -1);
+        v3 cam_normal = mulv3(nJ, ray_normal);
+        v3 n = normalize3(cam_normal);
+        o.normal[0] = n.x; o.normal[1] = n.y; o.normal[2] = n.z;
+    }
+}
+
+__global__ void __launch_bounds__(256) preprocess_kernel(
+    int P, int D, int M, const float *__restrict__ means, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ tongue,
+    const float *__restrict__ shs, const float *__restrict__ cov3D_precomp, const float *__restrict__ colors_precomp,
+    const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
+    float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size, int *__restrict__ radii,
+    float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
+    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, int gx, int gy)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    int out_radius = 0;
+    uint32_t out_tiles = 0;
+    do {
+        v3 p_orig = mk3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
+        v3 p_view = xform4x3(p_orig, view);
+        if (p_view.z <= 0.2f) break;  // near cull only (Q8)
+        float4 p_hom = xform4x4(p_orig, proj);
+        float p_w = 1.0f / (p_hom.w + 0.0000001f);
+        float ppx = p_hom.x * p_w, ppy = p_hom.y * p_w;
+        float cov3D[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            v3 sc = mk3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+            cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = cov3D[i];
+        Cov2DOut c2;
+        cov2d_planes(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, c2);
+        float ts = sqrtf(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
+        float cx = c2.cov[0], cy = c2.cov[1], cz = c2.cov[2];
+        float det = (cx * cz - cy * cy);
+        if (det == 0.0f) break;
+        float det_inv = 1.f / det;
+        float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+        float mid = 0.5f * (cx + cz);
+        float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        float pix_x = ndc2pix(ppx, W), pix_y = ndc2pix(ppy, H);
+        int2 rmin, rmax;
+        get_rect(pix_x, pix_y, (int)my_radius, gx, gy, rmin, rmax);
+        if ((rmax.x - rmin.x) * (rmax.y - rmin.y) == 0) break;
+        v3 rgb;
+        uint8_t cl = 0;
+        if (colors_precomp) {
+            rgb = mk3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
+        } else {
+            rgb = color_from_sh(D, p_orig, mk3(campos[0], campos[1], campos[2]), shs + (size_t)idx * M * 3, cl);
+        }
+        clamped[idx] = cl;
+        depths[idx] = p_view.z;
+        float4 *r4 = reinterpret_cast<float4 *>(rec + (size_t)idx * REC);
+        r4[0] = make_float4(pix_x, pix_y, conx, cony);
+        r4[1] = make_float4(conz, opacities[idx] * c2.coef, rgb.x, rgb.y);
+        r4[2] = make_float4(rgb.z, tongue[idx], ts, c2.ray_plane[0]);
+        r4[3] = make_float4(c2.ray_plane[1], c2.normal[0], c2.normal[1], c2.normal[2]);
+        float4 *c4 = reinterpret_cast<float4 *>(rec_coord + (size_t)idx * RECC);
+        c4[0] = make_float4(c2.cam_plane[0], c2.cam_plane[1], c2.cam_plane[2], c2.cam_plane[3]);
+        c4[1] = make_float4(c2.cam_plane[4], c2.cam_plane[5], p_view.x, p_view.y);
+        c4[2] = make_float4(p_view.z, 0.f, 0.f, 0.f);
+        out_radius = (int)my_radius;
+        out_tiles = (uint32_t)((rmax.y - rmin.y) * (rmax.x - rmin.x));
+    } while (0);
+    radii[idx] = out_radius;
+    tiles_touched[idx] = out_tiles;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means,
+                                                           const float *__restrict__ view, uint8_t *__restrict__ present)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    v3 pv = xform4x3(mk3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]), view);
+    present[idx] = !(pv.z <= 0.2f);
+}
+
+// K3: CR/rasterizer_impl.cu:70-111
+__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const float *__restrict__ rec,
+                                                                  const float *__restrict__ depths,
+                                                                  const uint32_t *__restrict__ offsets,
+                                                                  const int *__restrict__ radii, int gx, int gy,
+                                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ values)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    int rad = radii[idx];
+    if (rad > 0) {
+        uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
+        float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
+        int2 rmin, rmax;
+        get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
+        uint32_t dbits = __float_as_uint(depths[idx]);
+        for (int y = rmin.y; y < rmax.y; y++)
+            for (int x = rmin.x; x < rmax.x; x++) {
+                uint64_t key = (uint64_t)(uint32_t)(y * gx + x);
+                key <<= 32;
+                key |= dbits;
+                keys[off] = key;
+                values[off] = (uint32_t)idx;
+                off++;
+            }
+    }
+}
+
+// K5: CR/rasterizer_impl.cu:151-173
+__global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint64_t *__restrict__ keys,
+                                                                   uint32_t *__restrict__ ranges)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L) return;
+    uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[2 * currtile] = 0;
+    else {
+        uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+        if (currtile != prevtile) { ranges[2 * prevtile + 1] = idx; ranges[2 * currtile] = idx; }
+    }
+    if (idx == L - 1) ranges[2 * currtile + 1] = L;
+}
+
+void launch_preprocess(int P, int D, int M, const float *means, const float *scales, float scale_modifier,
+                       const float *rotations, const float *opacities, const float *tongue, const float *shs,
+                       const float *cov3D_precomp, const float *colors_precomp, const float *view, const float *proj,
+                       const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
+                       float kernel_size, int *radii, GeometryState g, hipStream_t s)
+{
+    int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
+                       scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
+                       campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
+                       g.depths, g.cov3D, g.clamped, g.tiles_touched, gx, gy);
+}
+
+void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, view, present);
+}
+
+void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint64_t *keys,
+                                uint32_t *values, hipStream_t s)
+{
+    int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.depths,
+                       g.point_offsets, radii, gx, gy, keys, values);
+}
+
+void launch_identify_tile_ranges(int R, const uint64_t *keys, uint32_t *ranges, hipStream_t s)
+{
+    if (R <= 0) return;
+    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, keys, ranges);
+}
+
+}  // namespace ed3

@@ -1,0 +1,227 @@
+// render_forward.hip -- K6: front-to-back alpha compositing of one 16x16 tile per wavefront.
+// Computes what CR/forward.cu:550-822 (renderCUDA<3,COORD,DEPTH,NORMAL>) computes -- colour, tongue, alpha,
+// expected/median coord + depth, normal, n_contrib (last, median) and the accumulators the backward needs --
+// with the blend rule of Q5-Q7.  Layout and scheduling are CDNA-native (see raster_common.h).
+#include "raster_common.h"
+
+namespace ed3 {
+
+template <bool COORD, bool DEPTH>
+__global__ void __launch_bounds__(64) render_forward_kernel(
+    int W, int H, int gx, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+    const float4 *__restrict__ rec, const float4 *__restrict__ rec_coord, float focal_x, float focal_y,
+    const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_coord,
+    float *__restrict__ out_mcoord, float *__restrict__ out_depth, float *__restrict__ out_mdepth,
+    float *__restrict__ out_alpha, float *__restrict__ out_tongue, float *__restrict__ out_normal,
+    uint32_t *__restrict__ n_contrib, float *__restrict__ accum_coord, float *__restrict__ accum_depth,
+    float *__restrict__ normal_length)
+{
+    constexpr bool GEO = COORD || DEPTH;
+    __shared__ float4 s_rec[64 * 4];
+    __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    const int px0 = tx * TILE + (lane & 3) * 4;
+    const int py = ty * TILE + (lane >> 2);
+    const size_t HW = (size_t)H * W;
+    const int nvalid = (py < H) ? max(0, min(4, W - px0)) : 0;  // pixels of this lane inside the image
+    const bool vec = (nvalid == 4) && ((W & 3) == 0);
+    const float fpy = (float)py;
+    float fpx[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) fpx[p] = (float)(px0 + p);
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    float T[4], C0[4], C1[4], C2[4], TG[4], WT[4];
+    float DP[4], MD[4], N0[4], N1[4], N2[4];
+    float CO0[4], CO1[4], CO2[4], MC0[4], MC1[4], MC2[4];
+    uint32_t last[4], maxc[4];
+    bool done[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        T[p] = 1.0f; C0[p] = C1[p] = C2[p] = TG[p] = WT[p] = 0.f;
+        DP[p] = MD[p] = N0[p] = N1[p] = N2[p] = 0.f;
+        CO0[p] = CO1[p] = CO2[p] = MC0[p] = MC1[p] = MC2[p] = 0.f;
+        last[p] = 0; maxc[p] = 0xFFFFFFFFu;
+        done[p] = !(p < nvalid);
+    }
+
+    bool finished = false;
+    for (int base = 0; base < n && !finished; base += 64) {
+        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        __syncthreads();
+        const int k = base + lane;
+        if (k < n) {
+            const uint32_t id = point_list[range.x + k];
+            const float4 *src = rec + (size_t)id * 4;
+            s_rec[lane * 4 + 0] = src[0];
+            s_rec[lane * 4 + 1] = src[1];
+            if (GEO) { s_rec[lane * 4 + 2] = src[2]; s_rec[lane * 4 + 3] = src[3]; }
+            else     { s_rec[lane * 4 + 2] = src[2]; }
+            if (COORD) {
+                const float4 *sc = rec_coord + (size_t)id * 3;
+                s_recc[lane * 3 + 0] = sc[0]; s_recc[lane * 3 + 1] = sc[1]; s_recc[lane * 3 + 2] = sc[2];
+            }
+        }
+        __syncthreads();
+        const int cnt = min(64, n - base);
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t contributor = (uint32_t)(base + j + 1);
+            const float4 r0 = s_rec[j * 4 + 0];  // x, y, cx, cy
+            const float4 r1 = s_rec[j * 4 + 1];  // cz, w, r, g
+            const float dy = r0.y - fpy;
+            const ConicRow cr = conic_row(r0.z, r0.w, r1.x, dy);
+            float dx[4], alpha[4];
+            bool valid[4];
+            bool any_valid = false;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                dx[p] = r0.x - fpx[p];
+                const float pw2 = conic_power2(cr, dx[p]);
+                const float G = gauss_G(pw2);
+                alpha[p] = gauss_alpha(r1.y, G);
+                valid[p] = !done[p] && !(pw2 > 0.0f) && !(alpha[p] < ALPHA_MIN);
+                any_valid |= valid[p];
+            }
+            if (!__any(any_valid)) continue;
+
+            const float4 r2 = s_rec[j * 4 + 2];  // b, tongue, ts, rpx
+            float4 r3 = make_float4(0, 0, 0, 0); // rpy, nx, ny, nz
+            if (GEO) r3 = s_rec[j * 4 + 3];
+            float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+            if (COORD) { q0 = s_recc[j * 3 + 0]; q1 = s_recc[j * 3 + 1]; q2 = s_recc[j * 3 + 2]; }
+            const float t_row = DEPTH ? (r2.z + r3.x * dy) : 0.f;  // ts + ray_plane.y*dy
+            bool any_term = false;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float test_T = T[p] * (1.0f - alpha[p]);
+                const bool term = valid[p] && (test_T < 0.0001f);
+                const bool blend = valid[p] && !term;
+                done[p] = done[p] || term;
+                any_term |= term;
+                const float aT = blend ? alpha[p] * T[p] : 0.0f;
+                C0[p] += r1.z * aT; C1[p] += r1.w * aT; C2[p] += r2.x * aT;
+                TG[p] += r2.y * aT;
+                const bool before_median = blend && (T[p] > 0.5f);
+                if (COORD) {
+                    const float c0 = q1.z + q0.x * dx[p] + q0.y * dy;
+                    const float c1 = q1.w + q0.z * dx[p] + q0.w * dy;
+                    const float c2 = q2.x + q1.x * dx[p] + q1.y * dy;
+                    CO0[p] += c0 * aT; CO1[p] += c1 * aT; CO2[p] += c2 * aT;
+                    MC0[p] = before_median ? c0 : MC0[p];
+                    MC1[p] = before_median ? c1 : MC1[p];
+                    MC2[p] = before_median ? c2 : MC2[p];
+                }
+                if (DEPTH) {
+                    const float t = t_row + r2.w * dx[p];
+                    DP[p] += t * aT;
+                    MD[p] = before_median ? t : MD[p];
+                }
+                if (GEO) {
+                    N0[p] += r3.y * aT; N1[p] += r3.z * aT; N2[p] += r3.w * aT;
+                    maxc[p] = before_median ? contributor : maxc[p];
+                }
+                WT[p] += aT;
+                T[p] = blend ? test_T : T[p];
+                last[p] = blend ? contributor : last[p];
+            }
+            if (__any(any_term)) {
+                if (__all(done[0] && done[1] && done[2] && done[3])) { finished = true; break; }
+            }
+        }
+    }
+
+    if (nvalid == 0) return;
+    const size_t pix0 = (size_t)py * W + px0;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    float v[4];
+    store4u(n_contrib, pix0, last, vec, nvalid);
+    store4u(n_contrib + HW, pix0, maxc, vec, nvalid);
+#pragma unroll
+    for (int p = 0; p < 4; p++) v[p] = C0[p] + T[p] * b0;
+    store4(out_color, pix0, v, vec, nvalid);
+#pragma unroll
+    for (int p = 0; p < 4; p++) v[p] = C1[p] + T[p] * b1;
+    store4(out_color + HW, pix0, v, vec, nvalid);
+#pragma unroll
+    for (int p = 0; p < 4; p++) v[p] = C2[p] + T[p] * b2;
+    store4(out_color + 2 * HW, pix0, v, vec, nvalid);
+    store4(out_tongue, pix0, TG, vec, nvalid);
+    store4(out_alpha, pix0, WT, vec, nvalid);
+
+    if (COORD) {
+        const float *CO[3] = {CO0, CO1, CO2};
+        const float *MC[3] = {MC0, MC1, MC2};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) v[p] = last[p] ? CO[ch][p] / WT[p] : 0.f;
+            store4(out_coord + ch * HW, pix0, v, vec, nvalid);
+            store4(accum_coord + ch * HW, pix0, CO[ch], vec, nvalid);
+            store4(out_mcoord + ch * HW, pix0, MC[ch], vec, nvalid);
+        }
+    }
+    if (DEPTH) {
+        float ln[4], dl[4];
+        const float pny = (fpy - H / 2.f) / focal_y;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float pnx = (fpx[p] - W / 2.f) / focal_x;
+            ln[p] = sqrtf(pnx * pnx + pny * pny + 1);
+            dl[p] = DP[p] / ln[p];
+        }
+        store4(accum_depth, pix0, dl, vec, nvalid);
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = last[p] ? dl[p] / WT[p] : 0.f;
+        store4(out_depth, pix0, v, vec, nvalid);
+#pragma unroll
+        for (int p = 0; p < 4; p++) v[p] = MD[p] / ln[p];
+        store4(out_mdepth, pix0, v, vec, nvalid);
+    }
+    if (GEO) {
+        float len[4], o0[4], o1[4], o2[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (last[p]) {
+                float l = sqrtf(N0[p] * N0[p] + N1[p] * N1[p] + N2[p] * N2[p]);
+                len[p] = l;
+                l = fmaxf(l, NORMALIZE_EPS);
+                o0[p] = N0[p] / l; o1[p] = N1[p] / l; o2[p] = N2[p] / l;
+            } else {
+                len[p] = 1.f; o0[p] = o1[p] = o2[p] = 0.f;
+            }
+        }
+        store4(normal_length, pix0, len, vec, nvalid);
+        store4(out_normal, pix0, o0, vec, nvalid);
+        store4(out_normal + HW, pix0, o1, vec, nvalid);
+        store4(out_normal + 2 * HW, pix0, o2, vec, nvalid);
+    }
+}
+
+void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
+                           const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,
+                           bool depth, float *out_color, float *out_coord, float *out_mcoord, float *out_depth,
+                           float *out_mdepth, float *out_alpha, float *out_tongue, float *out_normal, ImageState img,
+                           hipStream_t s)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    dim3 grid(gx * gy), block(64);
+#define ED3_FWD(C_, D_)                                                                                              \
+    hipLaunchKernelGGL((render_forward_kernel<C_, D_>), grid, block, 0, s, W, H, gx,                                 \
+                       reinterpret_cast<const uint2 *>(ranges), point_list, reinterpret_cast<const float4 *>(rec),  \
+                       reinterpret_cast<const float4 *>(rec_coord), focal_x, focal_y, bg, out_color, out_coord,      \
+                       out_mcoord, out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img.n_contrib,          \
+                       img.accum_coord, img.accum_depth, img.normal_length)
+    // variant dispatch as CR/forward.cu:863-870 (NORMAL on iff COORD or DEPTH)
+    if (coord && depth) ED3_FWD(true, true);
+    else if (coord) ED3_FWD(true, false);
+    else if (depth) ED3_FWD(false, true);
+    else ED3_FWD(false, false);
+#undef ED3_FWD
+}
+
+}  // namespace ed3

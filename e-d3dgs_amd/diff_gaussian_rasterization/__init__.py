@@ -1,0 +1,134 @@
+"""diff_gaussian_rasterization -- MI355X-native drop-in for the reference's rasterizer package.
+
+Public surface kept identical to DGR/diff_gaussian_rasterization/__init__.py so gaussian_renderer / train.py /
+render.py call it unchanged:
+  * GaussianRasterizationSettings: same 15 fields in the same order (:176-191)
+  * GaussianRasterizer(raster_settings)(means3D, means2D, opacities, tongue_class, shs, colors_precomp, scales,
+    rotations, cov3D_precomp) -> (color, radii, coord, mcoord, depth, mdepth, alpha, tongue, normal)  (:209-243, :105)
+  * GaussianRasterizer.markVisible(positions)  (:198-207)
+  * rasterize_gaussians(...) / _RasterizeGaussians autograd.Function with the reference's gradient slots (:161-172):
+    grads for means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp; None for
+    tongue_class (Q2) and raster_settings.
+The native code behind it is the C-ABI HIP library (include/ed3dgs.h) reached through `_C`.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    require_depth: bool
+    require_coord: bool
+    debug: bool
+
+
+def _snapshot(args):
+    return tuple(a.detach().cpu().clone() if torch.is_tensor(a) else a for a in args)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, tongue_class, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        call = (rs.bg, means3D, colors_precomp, opacities, tongue_class, scales, rotations, rs.scale_modifier,
+                cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.image_height,
+                rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.require_coord, rs.require_depth,
+                rs.debug)
+        if rs.debug:
+            # debug aid of the reference (:90-97): keep a CPU copy of the arguments and dump it if the call throws
+            saved = _snapshot(call)
+            try:
+                out = _C.rasterize_gaussians(*call)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians(*call)
+        (num_rendered, color, coord, mcoord, alpha, tongue, normal, depth, mdepth, radii, geom_buf, binning_buf,
+         img_buf) = out
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geom_buf,
+                              binning_buf, img_buf, alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, coord, mcoord, depth, mdepth, alpha, tongue, normal
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_coord, grad_mcoord, grad_depth, grad_mdepth, grad_alpha,
+                 grad_tongue, grad_normal):
+        # grad_radii and grad_tongue are ignored, as in the reference (:108)
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geom_buf, binning_buf, img_buf,
+         alpha) = ctx.saved_tensors
+        call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, grad_color, grad_coord,
+                grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal, normal, sh, rs.sh_degree, rs.campos,
+                geom_buf, ctx.num_rendered, binning_buf, img_buf, alpha, rs.require_coord, rs.require_depth, rs.debug)
+        if rs.debug:
+            saved = _snapshot(call)
+            try:
+                res = _C.rasterize_gaussians_backward(*call)
+            except Exception:
+                torch.save(saved, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            res = _C.rasterize_gaussians_backward(*call)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = res
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, None, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, tongue_class, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, tongue_class, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, tongue_class, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, tongue_class, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
+
+    def integrate(self, *args, **kwargs):
+        # GaussianRasterizer.integrate (:245-312) is the mesh-extraction probe: SURVEY 8(f) rank 1, not in this round.
+        return _C.integrate_gaussians_to_points(*args, **kwargs)

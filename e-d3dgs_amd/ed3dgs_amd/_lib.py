@@ -1,0 +1,65 @@
+"""Loader of the C-ABI HIP library (include/ed3dgs.h).  There is no CPU fallback: if the library is missing the
+import of any product module fails loudly."""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
+LIB_PATH = os.path.join(_CSRC, "libed3dgs_hip.so")
+_lib = None
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class DeformCfg(C.Structure):
+    _fields_ = [("P", C.c_int), ("W", C.c_int), ("D", C.c_int), ("E", C.c_int), ("TD", C.c_int), ("n_sh", C.c_int),
+                ("use_stage", C.c_int * 2), ("no_ds", C.c_int), ("no_dr", C.c_int), ("no_do", C.c_int),
+                ("no_dc", C.c_int), ("coef", C.c_float), ("coef_c", C.c_float), ("coef_o", C.c_float),
+                ("coef_s", C.c_float)]
+
+
+class StateView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "rec", "rec_coord", "depths", "cov3D", "clamped", "tiles_touched", "point_offsets", "point_list_keys",
+        "point_list", "ranges", "n_contrib", "accum_coord", "accum_depth", "normal_length")]
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libed3dgs_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, "-j8"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"ed3dgs_amd: HIP library {LIB_PATH} is missing -- run __graft_entry__.build() (or `make -C {_CSRC}`). "
+            "There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    L.ed3dgs_last_error.restype = C.c_char_p
+    L.ed3dgs_abi_version.restype = C.c_int
+    for n in ("ed3dgs_geometry_bytes", "ed3dgs_image_bytes", "ed3dgs_binning_bytes", "ed3dgs_backward_workspace_bytes",
+              "ed3dgs_deform_param_count", "ed3dgs_deform_workspace_bytes"):
+        getattr(L, n).restype = C.c_size_t
+    for n in ("ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible", "ed3dgs_state_view_get",
+              "ed3dgs_deform_forward", "ed3dgs_deform_backward"):
+        getattr(L, n).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTS = (
+    "ed3dgs_last_error", "ed3dgs_abi_version", "ed3dgs_geometry_bytes", "ed3dgs_image_bytes", "ed3dgs_binning_bytes",
+    "ed3dgs_backward_workspace_bytes", "ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible",
+    "ed3dgs_state_view_get", "ed3dgs_deform_param_count", "ed3dgs_deform_workspace_bytes", "ed3dgs_deform_forward",
+    "ed3dgs_deform_backward")
+
+
+def last_error():
+    return lib().ed3dgs_last_error().decode()

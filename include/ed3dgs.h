@@ -1,0 +1,184 @@
+/*
+ * ed3dgs.h -- C ABI of the MI355X-native (gfx950) E-D3DGS hot path: per-Gaussian deformation MLP +
+ * differentiable EWA-splat tile rasterizer.  Plain pointers and sizes only (no torch types); every pointer
+ * named "device" below is HBM memory of the current HIP device, `stream` is a hipStream_t (NULL = legacy
+ * default stream).  All entry points are stateless and enqueue on `stream`; forward performs exactly one
+ * blocking read-back (num_rendered), like the reference (CR/rasterizer_impl.cu:359).
+ *
+ * The entry points are what the reference's pybind layer binds for this path:
+ *   ed3dgs_rasterize_forward   <- CudaRasterizer::Rasterizer::forward   (CR/rasterizer.h:37-72,  CR/rasterizer_impl.cu:255-432)
+ *                                 as called by RasterizeGaussiansCUDA    (DGR/rasterize_points.cu:35-137)
+ *   ed3dgs_rasterize_backward  <- CudaRasterizer::Rasterizer::backward  (CR/rasterizer.h:105-150, CR/rasterizer_impl.cu:436-578)
+ *                                 as called by RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:139-250)
+ *   ed3dgs_mark_visible        <- CudaRasterizer::Rasterizer::markVisible (CR/rasterizer.h:22-27,  CR/rasterizer_impl.cu:176-188)
+ *   ed3dgs_deform_forward/backward <- deform_network.forward + autograd (scene/deformation.py:108-141), which the
+ *                                 reference runs as ~45 torch kernels; here one fused HIP launch per direction.
+ * See INTEGRATION.md for the reference-side binding.
+ *
+ * Return value: >= 0 on success (forward: num_rendered), < 0 on failure; ed3dgs_last_error() returns the
+ * message of the calling thread's last failure (AT_ERROR / std::runtime_error text in the reference).
+ */
+#ifndef ED3DGS_H_INCLUDED
+#define ED3DGS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ED3DGS_ERR_INVALID (-1) /* bad argument (shape / null / unsupported mode) */
+#define ED3DGS_ERR_HIP (-2)     /* a HIP runtime call or kernel failed             */
+#define ED3DGS_ERR_ALLOC (-3)   /* an allocation callback returned NULL            */
+
+/* Growable-buffer callback: must return a device pointer to at least `bytes` bytes, 128-byte aligned, that
+ * stays valid until the matching backward has run.  Mirrors std::function<char*(size_t)> of
+ * CR/rasterizer.h:38-40 / resizeFunctional (DGR/rasterize_points.cu:27-33). */
+typedef char *(*ed3dgs_alloc_fn)(void *user, size_t bytes);
+
+const char *ed3dgs_last_error(void);
+int ed3dgs_abi_version(void);
+
+/* Sizes of the three opaque state buffers (CR/rasterizer_impl.h:77-95 `required<T>`); layout is private. */
+size_t ed3dgs_geometry_bytes(int P);
+size_t ed3dgs_image_bytes(int width, int height);
+size_t ed3dgs_binning_bytes(int num_rendered);
+/* Scratch the backward needs (per-Gaussian gradient records accumulated by the tile pass). */
+size_t ed3dgs_backward_workspace_bytes(int P, int require_coord);
+
+/*
+ * Forward.  Pointer arguments (all device, fp32 unless noted):
+ *   background[3]; means3D[P,3]; shs[P,M,3] or NULL; colors_precomp[P,3] or NULL (exactly one of the two);
+ *   opacities[P]; tongue_class[P]; scales[P,3] + rotations[P,4] or NULL,NULL with cov3D_precomp[P,6];
+ *   viewmatrix[16], projmatrix[16]: the transposed (column-major) 4x4 the reference passes (CR/auxiliary.h:74-93);
+ *   cam_pos[3].  Outputs: out_color[3,H,W], out_coord[3,H,W], out_mcoord[3,H,W], out_depth[1,H,W],
+ *   out_mdepth[1,H,W], out_alpha[1,H,W], out_tongue[1,H,W], out_normal[3,H,W], radii[P] int32.
+ *   Planes a variant does not produce (coord/mcoord unless require_coord, depth/mdepth unless require_depth,
+ *   normal unless either) are left untouched: the caller zero-fills them (DGR/rasterize_points.cu:72-79).
+ * `prefiltered` is accepted and ignored, as in the reference (CR/rasterizer_impl.cu:349-350 passes `false`).
+ * debug != 0: synchronise and check after every stage (CR/auxiliary.h:404-411 CHECK_CUDA).
+ */
+int ed3dgs_rasterize_forward(
+    ed3dgs_alloc_fn geometry_alloc, void *geometry_user,
+    ed3dgs_alloc_fn binning_alloc, void *binning_user,
+    ed3dgs_alloc_fn image_alloc, void *image_user,
+    int P, int D, int M,
+    const float *background, int width, int height,
+    const float *means3D, const float *shs, const float *colors_precomp,
+    const float *opacities, const float *tongue_class,
+    const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float *out_color, float *out_coord, float *out_mcoord, float *out_depth, float *out_mdepth,
+    float *out_alpha, float *out_tongue, float *out_normal, int *radii,
+    int require_coord, int require_depth, int debug, void *stream);
+
+/*
+ * Backward.  Inputs as forward plus: R = num_rendered; alphas[1,H,W] and normalmap[3,H,W] = forward's out_alpha /
+ * out_normal; the three state buffers; upstream gradients dL_dpix[3,H,W], dL_dpix_coord[3,H,W],
+ * dL_dpix_mcoord[3,H,W], dL_dpix_depth[1,H,W], dL_dpix_mdepth[1,H,W], dL_dalphas[1,H,W], dL_dpix_normal[3,H,W]
+ * (coord pair read only if require_coord, depth pair only if require_depth, normal if either).
+ * Outputs (every element is written; no pre-zeroing needed): dL_dmean2D[P,3] (z = |dx|+|dy| abs-grad, Q9),
+ * dL_dcolor[P,3], dL_dopacity[P], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (if shs), dL_dscale[P,3],
+ * dL_drot[P,4] (if scales).  `workspace` replaces the reference's six caller-zeroed intermediate tensors
+ * (dL_dview_points, dL_dconic, dL_dts, dL_dcamera_planes, dL_dray_planes, dL_dnormals; DGR/rasterize_points.cu:184-194).
+ * q1_reference != 0 reproduces SURVEY quirk Q1 (mip-coefficient gradient uses dL_dconic.w as "combined opacity",
+ * CR/rasterizer_impl.cu:576); 0 uses the true conic_opacity.w.
+ */
+int ed3dgs_rasterize_backward(
+    int P, int D, int M, int R,
+    const float *background, int width, int height,
+    const float *means3D, const float *shs, const float *colors_precomp, const float *alphas,
+    const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size,
+    const int *radii, const float *normalmap,
+    char *geometry_buffer, char *binning_buffer, char *image_buffer,
+    const float *dL_dpix, const float *dL_dpix_coord, const float *dL_dpix_mcoord,
+    const float *dL_dpix_depth, const float *dL_dpix_mdepth, const float *dL_dalphas, const float *dL_dpix_normal,
+    float *dL_dmean2D, float *dL_dcolor, float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D,
+    float *dL_dsh, float *dL_dscale, float *dL_drot,
+    char *workspace, size_t workspace_bytes,
+    int require_coord, int require_depth, int q1_reference, int debug, void *stream);
+
+/* present[P] (1 byte each) = p_view.z > 0.2  (CR/rasterizer_impl.cu:54-66, CR/auxiliary.h:155-180) */
+int ed3dgs_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                        uint8_t *present, void *stream);
+
+/* Read-only views into the opaque state buffers, for parity tests (tile lists must match bit-exactly). */
+typedef struct ed3dgs_state_view {
+    const float *rec;             /* [P][16]: x,y, conic.xyz, opacity*coef, r,g,b, tongue, ts, ray_plane.xy, normal.xyz */
+    const float *rec_coord;       /* [P][12]: camera_plane[6], view_point[3], pad[3] */
+    const float *depths;          /* [P] */
+    const float *cov3D;           /* [P][6] */
+    const uint8_t *clamped;       /* [P] bit0..2 = r,g,b clamped */
+    const uint32_t *tiles_touched;/* [P] */
+    const uint32_t *point_offsets;/* [P] inclusive scan */
+    const uint64_t *point_list_keys;   /* [R] sorted */
+    const uint32_t *point_list;        /* [R] sorted Gaussian ids */
+    const uint32_t *ranges;       /* [T][2] */
+    const uint32_t *n_contrib;    /* [2][H][W] */
+    const float *accum_coord;     /* [3][H][W] */
+    const float *accum_depth;     /* [H][W] */
+    const float *normal_length;   /* [H][W] */
+} ed3dgs_state_view;
+int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geometry_buffer,
+                          const char *binning_buffer, const char *image_buffer, ed3dgs_state_view *out);
+
+/* ---------------- deformation MLP (scene/deformation.py) ---------------- */
+/* Network description: W = hidden width, D = trunk depth (D<=1: single Linear), E = gaussian embedding dim (32),
+ * TD = temporal embedding dim (256).  Parameter block layout (fp32, one per stage, `c` then `f`):
+ * see ed3dgs_deform_param_count(). */
+typedef struct ed3dgs_deform_cfg {
+    int P;            /* Gaussians */
+    int W;            /* net_width */
+    int D;            /* defor_depth */
+    int E;            /* gaussian_embedding_dim */
+    int TD;           /* temporal_embedding_dim */
+    int n_sh;         /* SH coefficients per Gaussian the rgb head updates (16) */
+    int use_stage[2]; /* [0] coarse (!no_coarse_deform), [1] fine (!no_fine_deform) */
+    int no_ds, no_dr, no_do, no_dc;
+    float coef, coef_c, coef_o, coef_s; /* anneal scalars, scene/deformation.py:119-123 */
+} ed3dgs_deform_cfg;
+
+/* floats in one stage's packed parameter block:
+ *  trunk0.weight[W][TD+E], trunk0.bias[W], (D-1) x { weight[W][W], bias[W] },
+ *  5 heads (pos, scales, rotations, opacity, rgb) x { l1.weight[W][W], l1.bias[W], l2.weight[n_k][W], l2.bias[n_k] },
+ *  n_k = 3,3,4,1,3*n_sh.  (state-dict order of scene/deformation.py:38-51) */
+size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *cfg);
+size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backward);
+
+/*
+ * Forward: h_t[2][TD] = temporal embedding rows already resampled at time t for stage c / f (host-side lerp of the
+ * 150x256 table, scene/deformation.py:53-67 -- 2 x 256 floats per frame); params[2] = packed stage blocks;
+ * embedding[P][E]; base tensors xyz[P,3], scales[P,3], rot[P,4], opacity[P], sh[P,n_sh,3].
+ * Outputs out_*: final values; sub_*: values after the coarse stage (the `extras[0]` tuple, :139-141); sub_* may be
+ * NULL.  `saved` (workspace from ed3dgs_deform_workspace_bytes(cfg,0)) keeps what backward needs.
+ */
+int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *h_t, const float *const params[2],
+                          const float *embedding, const float *xyz, const float *scales, const float *rot,
+                          const float *opacity, const float *sh,
+                          float *out_xyz, float *out_scales, float *out_rot, float *out_opacity, float *out_sh,
+                          float *sub_xyz, float *sub_scales, float *sub_rot, float *sub_opacity, float *sub_sh,
+                          char *saved, size_t saved_bytes, void *stream);
+
+/*
+ * Backward: g_* = dL/d(out_*) (NULL = zero), gs_* = dL/d(sub_*) (NULL = zero).
+ * Writes dL/d(params) into gparams[2] (accumulates: caller zero-fills), dL/dh_t into g_h_t[2][TD] (accumulates),
+ * dL/dembedding[P][E] (written).  Gradients w.r.t. the base tensors are g_* + gs_* (identity), left to the caller.
+ */
+int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *h_t, const float *const params[2],
+                           const float *embedding,
+                           const float *g_xyz, const float *g_scales, const float *g_rot, const float *g_opacity,
+                           const float *g_sh,
+                           const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
+                           const float *gs_sh,
+                           float *const gparams[2], float *g_h_t, float *g_embedding,
+                           const char *saved, size_t saved_bytes, char *workspace, size_t workspace_bytes,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""GPU parity: HIP rasterizer (through the C-ABI library) vs the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.md "Parity gate"):
+  * integer / index work bit-exact: radii, tiles_touched, scan, sort keys, per-tile sorted id lists, tile ranges,
+    depth bits, n_contrib;
+  * images within 1e-4 relative L-inf (relative to the plane's max magnitude) -- tolerance TOL_IMG below;
+  * gradients within TOL_GRAD relative L-inf (fp32 atomics sum in arbitrary order; the oracle sums in fp64).
+Pixels whose oracle "decision margin" is below MARGIN are excluded from the image check: at such a pixel a blend
+decision (alpha >= 1/255, T*(1-alpha) < 1e-4, T > 0.5) sits within float rounding of its threshold, the rendered
+value is discontinuous there, and any two correct implementations (including two builds of the reference) may
+differ.  The excluded fraction is asserted to be tiny.
+"""
+import numpy as np
+import pytest
+import torch
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+TOL_IMG = 1e-4
+TOL_GRAD = 2e-4
+MARGIN = 2e-5
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _check_state(fw, out, sv):
+    assert out[0] == fw["num_rendered"]
+    np.testing.assert_array_equal(out[9].cpu().numpy(), fw["radii"])
+    np.testing.assert_array_equal(sv["tiles_touched"], fw["tiles_touched"])
+    np.testing.assert_array_equal(sv["point_offsets"], fw["point_offsets"])
+    np.testing.assert_array_equal(sv["keys"], fw["keys"])
+    np.testing.assert_array_equal(sv["point_list"], fw["point_list"])
+    np.testing.assert_array_equal(sv["ranges"], fw["ranges"])
+    vis = fw["radii"] > 0
+    np.testing.assert_array_equal(sv["depths"][vis].view(np.uint32), fw["depths"][vis].view(np.uint32))
+    rec = sv["rec"][vis]
+    np.testing.assert_array_equal(rec[:, 0:2], fw["means2D"][vis])
+    np.testing.assert_array_equal(rec[:, 2:6], fw["conic_opacity"][vis])
+    np.testing.assert_array_equal(rec[:, 6:9], fw["rgb"][vis])
+    np.testing.assert_array_equal(rec[:, 10], fw["ts"][vis])
+    # plane / normal terms go through the iterative eigen-solver: same algorithm, compared tightly
+    np.testing.assert_allclose(rec[:, 11:13], fw["ray_planes"][vis], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rec[:, 13:16], fw["normals"][vis], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sv["rec_coord"][vis][:, 0:6], fw["camera_planes"][vis], rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(sv["rec_coord"][vis][:, 6:9], fw["view_points"][vis])
+    np.testing.assert_array_equal(sv["cov3D"][vis], fw["cov3D"][vis])
+
+
+def _check_images(fw, out, variant):
+    rc, rd = util.VARIANTS[variant]
+    (_, color, coord, mcoord, alpha, tongue, normal, depth, mdepth) = [o.cpu().numpy() if torch.is_tensor(o) else o for o in out[:9]]
+    good = fw["margin"] >= MARGIN
+    frac_bad = 1.0 - good.mean()
+    assert frac_bad < 5e-3, frac_bad
+    errs = {}
+    errs["color"] = util.rel_linf(color, fw["color"], good)
+    errs["alpha"] = util.rel_linf(alpha, fw["alpha"], good)
+    errs["tongue"] = util.rel_linf(tongue, fw["tongue"], good) if np.abs(fw["tongue"]).max() > 0 else 0.0
+    if rd:
+        errs["depth"] = util.rel_linf(depth, fw["depth"], good)
+        errs["mdepth"] = util.rel_linf(mdepth, fw["mdepth"], good)
+    if rc:
+        errs["coord"] = util.rel_linf(coord, fw["coord"], good)
+        errs["mcoord"] = util.rel_linf(mcoord, fw["mcoord"], good)
+    if rc or rd:
+        errs["normal"] = util.rel_linf(normal, fw["normal"], good)
+    else:
+        assert np.abs(normal).max() == 0 and np.abs(depth).max() == 0 and np.abs(coord).max() == 0
+    for k, v in errs.items():
+        assert v <= TOL_IMG, (k, v, errs)
+    return errs, frac_bad
+
+
+@pytest.mark.parametrize("variant", ["FFF", "FTT", "TFT", "TTT"])
+def test_forward_parity_c1(variant):
+    """BASELINE config C1: 10k Gaussians, 400x400."""
+    _need_gpu()
+    inp = util.scene_inputs(10000, 400, 400, tongue=True)
+    fw = util.oracle_forward(inp, variant)
+    out, sv = util.hip_forward_raw(inp, variant)
+    _check_state(fw, out, sv)
+    errs, frac = _check_images(fw, out, variant)
+    good = fw["margin"] >= MARGIN
+    np.testing.assert_array_equal(sv["n_contrib"][0][good], fw["n_contrib"][0][good])
+    if variant != "FFF":
+        np.testing.assert_array_equal(sv["n_contrib"][1][good], fw["n_contrib"][1][good])
+    print(variant, "fwd rel-Linf", errs, "excluded px frac", frac)
+
+
+@pytest.mark.parametrize("W,H", [(397, 203), (1100, 1604)])
+def test_forward_ragged_sizes(W, H):
+    """Image sizes that are not multiples of 16 / 4 (partial tiles, scalar store path) and the NeRSemble shape."""
+    _need_gpu()
+    inp = util.scene_inputs(5000, W, H, scene_seed=3, cam_seed=4, kernel_size=0.3)
+    fw = util.oracle_forward(inp, "TTT")
+    out, sv = util.hip_forward_raw(inp, "TTT")
+    _check_state(fw, out, sv)
+    _check_images(fw, out, "TTT")
+
+
+def test_forward_colors_precomp_and_cov3d():
+    _need_gpu()
+    inp = util.scene_inputs(4000, 320, 240, scene_seed=5)
+    g = torch.Generator().manual_seed(11)
+    colors = torch.rand(inp["P"], 3, generator=g)
+    fw0 = util.oracle_forward(inp, "FTT")
+    cov = torch.from_numpy(fw0["cov3D"].copy())  # cov3D built by the oracle from scale/rot
+    fw = util.oracle_forward(inp, "FTT", colors_precomp=colors, cov3D_precomp=cov)
+    out, sv = util.hip_forward_raw(inp, "FTT", colors_precomp=colors, cov3D_precomp=cov)
+    _check_state(fw, out, sv)
+    _check_images(fw, out, "FTT")
+
+
+def _grad_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("variant,ks", [("FFF", 0.0), ("FTT", 0.0), ("TFT", 0.0), ("TTT", 0.3)])
+def test_backward_parity_c1(variant, ks):
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    from ed3dgs_amd import synthetic as S
+    inp = util.scene_inputs(10000, 400, 400, kernel_size=ks)
+    H, W = inp["H"], inp["W"]
+    grads = S.make_upstream_grads(H, W)
+    rc, rd = util.VARIANTS[variant]
+    if not rc:
+        grads["coord"].zero_(); grads["mcoord"].zero_()
+    if not rd:
+        grads["depth"].zero_(); grads["mdepth"].zero_()
+    if not (rc or rd):
+        grads["normal"].zero_()
+    fw = util.oracle_forward(inp, variant)
+    bw = util.oracle_backward(inp, fw, grads, variant)
+    out, sv = util.hip_forward_raw(inp, variant)
+    d = lambda t: t.cuda().contiguous()
+    e = torch.Tensor([])
+    res = _C.rasterize_gaussians_backward(
+        d(inp["bg"]), d(inp["means3D"]), out[9], e, d(inp["scales"]), d(inp["rotations"]), inp["scale_modifier"], e,
+        d(inp["viewmatrix"]), d(inp["projmatrix"]), inp["tanfovx"], inp["tanfovy"], inp["kernel_size"],
+        d(grads["color"]), d(grads["coord"]), d(grads["mcoord"]), d(grads["depth"]), d(grads["mdepth"]),
+        d(grads["alpha"]), d(grads["normal"]), out[6], d(inp["shs"]), inp["sh_degree"], d(inp["campos"]), out[10],
+        out[0], out[11], out[12], out[4], rc, rd, False)
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+    errs = {}
+    for n, t in zip(names, res):
+        got = t.cpu().numpy().reshape(bw[n].shape)
+        assert np.isfinite(got).all(), n
+        errs[n] = _grad_err(got, bw[n])
+    print(variant, "bwd rel-Linf", errs)
+    for n, v in errs.items():
+        assert v <= TOL_GRAD, (n, v, errs)
+
+
+def test_autograd_function_and_module_surface():
+    """GaussianRasterizer module: 9-tuple order, gradient slots, mark_visible, XOR validation errors."""
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    inp = util.scene_inputs(3000, 256, 192, scene_seed=9)
+    rs = util.hip_settings(inp, "FTT")
+    rast = GaussianRasterizer(rs)
+    leaf = lambda t: t.cuda().clone().requires_grad_(True)
+    means3D, opac, scales, rots, shs = leaf(inp["means3D"]), leaf(inp["opacities"]), leaf(inp["scales"]), leaf(inp["rotations"]), leaf(inp["shs"])
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    outs = rast(means3D=means3D, means2D=means2D, opacities=opac, tongue_class=inp["tongue_class"].cuda(), shs=shs,
+                scales=scales, rotations=rots)
+    assert len(outs) == 9
+    color, radii, coord, mcoord, depth, mdepth, alpha, tongue, normal = outs
+    assert color.shape == (3, 192, 256) and radii.dtype == torch.int32 and depth.shape == (1, 192, 256)
+    loss = color.mean() + depth.mean() * 0.1 + normal.sum() * 1e-3 + alpha.mean()
+    loss.backward()
+    for t in (means3D, means2D, opac, scales, rots, shs):
+        assert t.grad is not None and torch.isfinite(t.grad).all()
+    assert means2D.grad.shape == (3000, 3) and (means2D.grad[:, 2] >= 0).all()
+    vis = rast.markVisible(inp["means3D"].cuda())
+    from oracle import raster_oracle as O
+    np.testing.assert_array_equal(vis.cpu().numpy(), O.mark_visible(inp["means3D"].numpy(), inp["viewmatrix"].numpy(), inp["projmatrix"].numpy()))
+    with pytest.raises(Exception):
+        rast(means3D=means3D, means2D=means2D, opacities=opac, tongue_class=inp["tongue_class"].cuda())
+    with pytest.raises(Exception):
+        rast(means3D=means3D, means2D=means2D, opacities=opac, tongue_class=inp["tongue_class"].cuda(), shs=shs, scales=scales)
+    with pytest.raises(RuntimeError):
+        from diff_gaussian_rasterization import _C
+        _C.rasterize_gaussians(rs.bg, means3D.detach().reshape(-1), torch.Tensor([]), opac.detach(), inp["tongue_class"].cuda(),
+                               scales.detach(), rots.detach(), 1.0, torch.Tensor([]), rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                               rs.tanfovy, 0.0, 192, 256, shs.detach(), 3, rs.campos, False, False, True, False)
+
+
+def test_empty_and_culled_inputs():
+    """P = 0 short-circuits to zero images; every Gaussian behind the camera renders the background only."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    inp = util.scene_inputs(64, 128, 96)
+    e = torch.Tensor([])
+    d = lambda t: t.cuda().contiguous()
+    out = _C.rasterize_gaussians(d(inp["bg"]), torch.zeros(0, 3).cuda(), e, torch.zeros(0, 1).cuda(), torch.zeros(0, 1).cuda(),
+                                 torch.zeros(0, 3).cuda(), torch.zeros(0, 4).cuda(), 1.0, e, d(inp["viewmatrix"]), d(inp["projmatrix"]),
+                                 inp["tanfovx"], inp["tanfovy"], 0.0, 96, 128, torch.zeros(0, 16, 3).cuda(), 3, d(inp["campos"]),
+                                 False, True, True, False)
+    assert out[0] == 0 and float(out[1].abs().max()) == 0.0
+    inp2 = dict(inp)
+    inp2["means3D"] = inp["means3D"] + inp["campos"][None, :] * 3.0  # pushes everything behind the camera
+    fw = util.oracle_forward(inp2, "FTT")
+    assert fw["num_rendered"] == 0
+    out2, sv = util.hip_forward_raw(inp2, "FTT")
+    assert out2[0] == 0
+    np.testing.assert_array_equal(out2[9].cpu().numpy(), fw["radii"])
+    np.testing.assert_allclose(out2[1].cpu().numpy(), fw["color"])
+    assert float(out2[4].abs().max()) == 0.0

@@ -1,0 +1,85 @@
+"""Shared helpers of the parity tests: run the same synthetic inputs through the CPU oracle and the HIP path."""
+import math
+
+import numpy as np
+import torch
+
+from ed3dgs_amd import synthetic as S
+
+VARIANTS = {"FFF": (False, False), "FTT": (False, True), "TFT": (True, False), "TTT": (True, True)}
+
+
+def scene_inputs(P, W, H, scene_seed=0, cam_seed=1, cam_index=0, n_cams=1, kernel_size=0.0, tongue=False):
+    sc = S.make_scene(P, seed=scene_seed)
+    cam = S.make_cameras(n_cams, W, H, seed=cam_seed)[cam_index]
+    a = S.activated(sc)
+    if tongue:
+        g = torch.Generator().manual_seed(7)
+        sc.tongue_class = (torch.rand(P, 1, generator=g) > 0.5).float()
+    return dict(
+        P=P, W=W, H=H, bg=torch.ones(3), means3D=sc.xyz, opacities=a["opacities"], tongue_class=sc.tongue_class,
+        scales=a["scales"], rotations=a["rotations"], shs=a["shs"], viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, campos=cam.camera_center, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=kernel_size, scale_modifier=1.0, sh_degree=3)
+
+
+def oracle_forward(inp, variant, with_margin=True, colors_precomp=None, cov3D_precomp=None):
+    from oracle import raster_oracle as O
+    rc, rd = VARIANTS[variant]
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    use_cov = cov3D_precomp is not None
+    return O.forward(n(inp["bg"]), n(inp["means3D"]), n(colors_precomp), n(inp["opacities"]), n(inp["tongue_class"]),
+                     None if use_cov else n(inp["scales"]), None if use_cov else n(inp["rotations"]),
+                     inp["scale_modifier"], n(cov3D_precomp), n(inp["viewmatrix"]), n(inp["projmatrix"]),
+                     inp["tanfovx"], inp["tanfovy"], inp["kernel_size"], inp["H"], inp["W"],
+                     None if colors_precomp is not None else n(inp["shs"]), inp["sh_degree"], n(inp["campos"]), rc, rd,
+                     with_margin=with_margin)
+
+
+def oracle_backward(inp, fw, grads, variant, colors_precomp=None, cov3D_precomp=None, reference_q1=True):
+    from oracle import raster_oracle as O
+    rc, rd = VARIANTS[variant]
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    use_cov = cov3D_precomp is not None
+    return O.backward(fw, n(inp["bg"]), n(inp["means3D"]), n(colors_precomp), None if use_cov else n(inp["scales"]),
+                      None if use_cov else n(inp["rotations"]), inp["scale_modifier"], n(cov3D_precomp),
+                      n(inp["viewmatrix"]), n(inp["projmatrix"]), inp["tanfovx"], inp["tanfovy"], inp["kernel_size"],
+                      n(grads["color"]), n(grads["coord"]), n(grads["mcoord"]), n(grads["depth"]), n(grads["mdepth"]),
+                      n(grads["alpha"]), n(grads["normal"]), None if colors_precomp is not None else n(inp["shs"]),
+                      inp["sh_degree"], n(inp["campos"]), rc, rd, reference_q1=reference_q1)
+
+
+def hip_settings(inp, variant, device="cuda", debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    rc, rd = VARIANTS[variant]
+    return GaussianRasterizationSettings(
+        image_height=inp["H"], image_width=inp["W"], tanfovx=inp["tanfovx"], tanfovy=inp["tanfovy"],
+        kernel_size=inp["kernel_size"], bg=inp["bg"].to(device), scale_modifier=inp["scale_modifier"],
+        viewmatrix=inp["viewmatrix"].to(device), projmatrix=inp["projmatrix"].to(device), sh_degree=inp["sh_degree"],
+        campos=inp["campos"].to(device), prefiltered=False, require_depth=rd, require_coord=rc, debug=debug)
+
+
+def hip_forward_raw(inp, variant, device="cuda", colors_precomp=None, cov3D_precomp=None):
+    """Calls _C.rasterize_gaussians directly; returns the 13-tuple and a state view."""
+    from diff_gaussian_rasterization import _C
+    rc, rd = VARIANTS[variant]
+    d = lambda t: t.to(device).contiguous()
+    e = torch.Tensor([])
+    use_cov = cov3D_precomp is not None
+    out = _C.rasterize_gaussians(
+        d(inp["bg"]), d(inp["means3D"]), e if colors_precomp is None else d(colors_precomp), d(inp["opacities"]),
+        d(inp["tongue_class"]), e if use_cov else d(inp["scales"]), e if use_cov else d(inp["rotations"]),
+        inp["scale_modifier"], d(cov3D_precomp) if use_cov else e, d(inp["viewmatrix"]), d(inp["projmatrix"]),
+        inp["tanfovx"], inp["tanfovy"], inp["kernel_size"], inp["H"], inp["W"],
+        e if colors_precomp is not None else d(inp["shs"]), inp["sh_degree"], d(inp["campos"]), False, rc, rd, False)
+    sv = _C.state_view(inp["P"], inp["H"], inp["W"], out[0], out[10], out[11], out[12])
+    return out, sv
+
+
+def rel_linf(a, b, mask=None):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    d = np.abs(a - b)
+    if mask is not None:
+        d = d[..., mask] if d.ndim > mask.ndim else d[mask]
+    scale = max(np.abs(b).max(), 1e-30)
+    return d.max() / scale if d.size else 0.0
