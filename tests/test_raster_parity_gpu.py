@@ -19,7 +19,8 @@ import util
 pytestmark = pytest.mark.gpu
 
 TOL_IMG = 1e-4
-TOL_GRAD = 2e-4
+TOL_GRAD = 5e-5      # backward kernels alone: oracle backward fed with the HIP forward's saved state
+TOL_GRAD_E2E = 2e-3  # forward+backward end to end (see test_backward_parity_c1 docstring)
 MARGIN = 2e-5
 
 
@@ -28,7 +29,7 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _check_state(fw, out, sv):
+def _check_state(fw, out, sv, colors=None, cov=None):
     assert out[0] == fw["num_rendered"]
     np.testing.assert_array_equal(out[9].cpu().numpy(), fw["radii"])
     np.testing.assert_array_equal(sv["tiles_touched"], fw["tiles_touched"])
@@ -41,14 +42,14 @@ def _check_state(fw, out, sv):
     rec = sv["rec"][vis]
     np.testing.assert_array_equal(rec[:, 0:2], fw["means2D"][vis])
     np.testing.assert_array_equal(rec[:, 2:6], fw["conic_opacity"][vis])
-    np.testing.assert_array_equal(rec[:, 6:9], fw["rgb"][vis])
+    np.testing.assert_array_equal(rec[:, 6:9], (fw["rgb"] if colors is None else colors.numpy())[vis])
     np.testing.assert_array_equal(rec[:, 10], fw["ts"][vis])
     # plane / normal terms go through the iterative eigen-solver: same algorithm, compared tightly
     np.testing.assert_allclose(rec[:, 11:13], fw["ray_planes"][vis], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(rec[:, 13:16], fw["normals"][vis], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(sv["rec_coord"][vis][:, 0:6], fw["camera_planes"][vis], rtol=1e-5, atol=1e-7)
     np.testing.assert_array_equal(sv["rec_coord"][vis][:, 6:9], fw["view_points"][vis])
-    np.testing.assert_array_equal(sv["cov3D"][vis], fw["cov3D"][vis])
+    np.testing.assert_array_equal(sv["cov3D"][vis], (fw["cov3D"] if cov is None else cov.numpy())[vis])
 
 
 def _check_images(fw, out, variant):
@@ -112,7 +113,7 @@ def test_forward_colors_precomp_and_cov3d():
     cov = torch.from_numpy(fw0["cov3D"].copy())  # cov3D built by the oracle from scale/rot
     fw = util.oracle_forward(inp, "FTT", colors_precomp=colors, cov3D_precomp=cov)
     out, sv = util.hip_forward_raw(inp, "FTT", colors_precomp=colors, cov3D_precomp=cov)
-    _check_state(fw, out, sv)
+    _check_state(fw, out, sv, colors, cov)
     _check_images(fw, out, "FTT")
 
 
@@ -123,6 +124,14 @@ def _grad_err(a, b):
 
 @pytest.mark.parametrize("variant,ks", [("FFF", 0.0), ("FTT", 0.0), ("TFT", 0.0), ("TTT", 0.3)])
 def test_backward_parity_c1(variant, ks):
+    """Two comparisons.
+    (1) kernel level: the oracle backward is fed the HIP forward's own saved state (alpha, n_contrib, accumulators,
+        normal map), so both backwards start from identical inputs -> TOL_GRAD.
+    (2) end to end: oracle forward + oracle backward vs HIP forward + HIP backward -> TOL_GRAD_E2E.  Looser because
+        the reference's algorithm restarts the transmittance from T_final = 1 - alpha_out (CR/backward.cu:706): for a
+        nearly opaque pixel (T_final down to 1e-4) a 1e-7 absolute difference in the forward's alpha sum is a 1e-3
+        relative difference in every reconstructed T of that pixel.  That sensitivity belongs to the algorithm, not
+        to either implementation."""
     _need_gpu()
     from diff_gaussian_rasterization import _C
     from ed3dgs_amd import synthetic as S
@@ -137,8 +146,12 @@ def test_backward_parity_c1(variant, ks):
     if not (rc or rd):
         grads["normal"].zero_()
     fw = util.oracle_forward(inp, variant)
-    bw = util.oracle_backward(inp, fw, grads, variant)
+    bw_e2e = util.oracle_backward(inp, fw, grads, variant)
     out, sv = util.hip_forward_raw(inp, variant)
+    fw_hip = dict(fw)
+    fw_hip.update(alpha=out[4].cpu().numpy(), normal=out[6].cpu().numpy(), n_contrib=sv["n_contrib"],
+                  accum_coord=sv["accum_coord"], accum_depth=sv["accum_depth"], normal_length=sv["normal_length"])
+    bw = util.oracle_backward(inp, fw_hip, grads, variant)
     d = lambda t: t.cuda().contiguous()
     e = torch.Tensor([])
     res = _C.rasterize_gaussians_backward(
@@ -148,14 +161,18 @@ def test_backward_parity_c1(variant, ks):
         d(grads["alpha"]), d(grads["normal"]), out[6], d(inp["shs"]), inp["sh_degree"], d(inp["campos"]), out[10],
         out[0], out[11], out[12], out[4], rc, rd, False)
     names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
-    errs = {}
+    errs, errs_e2e = {}, {}
     for n, t in zip(names, res):
         got = t.cpu().numpy().reshape(bw[n].shape)
         assert np.isfinite(got).all(), n
         errs[n] = _grad_err(got, bw[n])
-    print(variant, "bwd rel-Linf", errs)
+        errs_e2e[n] = _grad_err(got, bw_e2e[n])
+    print(variant, "bwd kernel-level rel-Linf", errs)
+    print(variant, "bwd end-to-end  rel-Linf", errs_e2e)
     for n, v in errs.items():
         assert v <= TOL_GRAD, (n, v, errs)
+    for n, v in errs_e2e.items():
+        assert v <= TOL_GRAD_E2E, (n, v, errs_e2e)
 
 
 def test_autograd_function_and_module_surface():
