@@ -1,23 +1,895 @@
-// deform.hip -- fused per-Gaussian deformation MLP (scene/deformation.py).  TEMPORARY: entry points only.
+// deform.hip -- per-Gaussian deformation MLP of E-D3DGS (scene/deformation.py:15-141) for gfx950.
+//
+// What is computed: the reference's coarse + fine stages, each = trunk Linear([h_t | emb_g]) followed by five heads
+// Linear(ReLU) -> Linear(ReLU) with residual updates (deform :90-106); h_t is the frame's temporal row
+// (get_temporal_embed :53-67), identical for all Gaussians, so its part of the trunk is hoisted to a per-frame
+// vector hb = W1[:, :TD] h_t + b1.
+//
+// How (CDNA4-native, not the reference's 45 torch kernels):
+//  * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in the TRANSPOSED formulation D[out_feature][gaussian] = W * X, so the
+//    accumulator of one layer (feature on the register index, Gaussian on the lane) is directly the B operand of the
+//    next layer: a wave carries a strip of 32 Gaussians through trunk -> head hidden -> head output entirely in
+//    registers, no LDS round trip, no activation ever written to HBM in the forward;
+//  * weights are re-laid once per call into MFMA A-fragment order (one coalesced 256-byte load per MFMA), with the
+//    k-slot permutation f(kk,h) = (kk&3) + 8(kk>>2) + 4h that matches the accumulator's register->feature map;
+//  * backward recomputes the activations per strip, produces the input gradients in registers, stores only what the
+//    weight-gradient reductions need, and reduces dW = G^T X with the same MFMA over split Gaussian ranges.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+
 #include "common.h"
 
+namespace ed3 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NHEAD = 5;
+constexpr int OTMAX = 2;   // output tiles of 32 per head (rgb: 48 -> 2)
+constexpr int FS_STRIDE = 1024;  // floats of frame state per stage (h, dh/dt need TD <= 448)
+
+__device__ __forceinline__ int fslot(int kk, int h) { return (kk & 3) + 8 * (kk >> 2) + 4 * h; }
+__host__ __device__ inline int head_nk(int k, int n_sh) { return k == 0 ? 3 : k == 1 ? 3 : k == 2 ? 4 : k == 3 ? 1 : 3 * n_sh; }
+
+struct ParamLayout {
+    size_t W1, b1, W2[NHEAD], b2[NHEAD], W3[NHEAD], b3[NHEAD], total;
+};
+__host__ __device__ inline ParamLayout param_layout(int W, int TD, int E, int n_sh)
+{
+    ParamLayout L;
+    size_t o = 0;
+    L.W1 = o; o += (size_t)W * (TD + E);
+    L.b1 = o; o += W;
+    for (int k = 0; k < NHEAD; k++) {
+        int nk = head_nk(k, n_sh);
+        L.W2[k] = o; o += (size_t)W * W;
+        L.b2[k] = o; o += W;
+        L.W3[k] = o; o += (size_t)nk * W;
+        L.b3[k] = o; o += nk;
+    }
+    L.total = o;
+    return L;
+}
+
+// fragment workspace of one stage (float offsets)
+struct FragLayout {
+    size_t F1, F2, F3, B2, B3, HB, F1T, F2T, F3T, total;
+};
+__host__ __device__ inline FragLayout frag_layout(int W, int E, bool bwd)
+{
+    FragLayout L;
+    size_t o = 0;
+    L.F1 = o; o += (size_t)W * E;
+    L.F2 = o; o += (size_t)NHEAD * W * W;
+    L.F3 = o; o += (size_t)NHEAD * OTMAX * 32 * W;
+    L.B2 = o; o += (size_t)NHEAD * W;
+    L.B3 = o; o += (size_t)NHEAD * OTMAX * 32;
+    L.HB = o; o += W;
+    L.F1T = o; if (bwd) o += (size_t)W * E;
+    L.F2T = o; if (bwd) o += (size_t)NHEAD * W * W;
+    L.F3T = o; if (bwd) o += (size_t)NHEAD * OTMAX * 32 * W;
+    L.total = (o + 63) & ~(size_t)63;
+    return L;
+}
+
+struct DeformDev {
+    int P, W, E, TD, n_sh, NT, ET;
+    int nk[NHEAD], ot[NHEAD], enabled[NHEAD];
+    int use_stage[2];
+    float hc[NHEAD];  // residual scale per head (:92-105)
+    const float *frag[2];   // fragment workspace per stage
+    FragLayout fl;
+    const float *emb, *xyz, *scales, *rot, *opacity, *sh;
+    float *out[5], *sub[5];
+    // backward
+    const float *g[5], *gs[5];
+    float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
+    float *g_emb;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// per-frame kernel: time offset, temporal row h (lerp of <= 4 table rows), dh/dt, and hb = W1[:, :TD] h + b1
+// frame state per stage (floats): [0..TD) h, [TD..2TD) dh/dt, then 4 row ids (as int bits), 4 coefs
+// ------------------------------------------------------------------------------------------------------------
+struct FrameArgs {
+    int W, E, TD, max_emb, num_offsets, cam_no;
+    int use_stage[2], n_rows[2];
+    float time;
+    const float *table, *offsets;
+    const float *params[2];
+    size_t W1_off, b1_off;
+    float *fs;        // [2][FS_STRIDE]
+    float *hb[2];     // -> frag workspace HB
+};
+
+__device__ inline void temporal_setup(const FrameArgs &a, int s, float t, int rows[4], float coefs[4], float &slope,
+                                      int yrow[2])
+{
+    // grid_sample(bilinear, align_corners=True, padding_mode='reflection') on the row-resized table, restated in
+    // fp32: y = reflect(t * (n-1)) in [0, n-1]; resized row yy = lerp(table, yy * (E-1)/(n-1)).
+    const int n = a.n_rows[s], Emb = a.max_emb;
+    float gy = (t - 0.5f) * 2.f;
+    float iy = ((gy + 1.f) / 2.f) * (float)(n - 1);
+    float sgn = 1.f;
+    if (n > 1) {
+        const float span = (float)(n - 1);
+        float x = fabsf(iy);
+        if (iy < 0) sgn = -sgn;
+        float extra = fmodf(x, span);
+        int flips = (int)floorf(x / span);
+        if (flips & 1) { iy = span - extra; sgn = -sgn; } else { iy = extra; }
+    } else {
+        iy = 0.f; sgn = 0.f;
+    }
+    if (iy < 0.f) { iy = 0.f; sgn = 0.f; }
+    if (iy > (float)(n - 1)) { iy = (float)(n - 1); sgn = 0.f; }
+    int y0 = (int)floorf(iy);
+    int y1 = y0 + 1;
+    float wy1 = iy - (float)y0, wy0 = 1.f - wy1;
+    bool y1ok = y1 <= n - 1;
+    if (!y1ok) { y1 = n - 1; }
+    yrow[0] = y0; yrow[1] = y1;
+    const float scale = n > 1 ? (float)(Emb - 1) / (float)(n - 1) : 0.f;
+    for (int q = 0; q < 2; q++) {
+        int yy = q ? y1 : y0;
+        float wy = q ? (y1ok ? wy1 : 0.f) : wy0;
+        float src = (float)yy * scale;
+        int i0 = min((int)floorf(src), Emb - 1);
+        int i1 = min(i0 + 1, Emb - 1);
+        float l1 = src - (float)i0, l0 = 1.f - l1;
+        rows[2 * q] = i0; rows[2 * q + 1] = i1;
+        coefs[2 * q] = wy * l0; coefs[2 * q + 1] = wy * l1;
+    }
+    slope = sgn * (float)(n - 1);  // d(iy)/dt
+}
+
+__device__ inline float frame_time(const FrameArgs &a)
+{
+    float off;
+    if (a.cam_no < 0) {  // mean of the non-zero offsets, NaN -> 0 (scene/deformation.py:112-114)
+        float sum = 0.f; int cnt = 0;
+        for (int i = 0; i < a.num_offsets; i++) { float v = a.offsets[i]; if (v != 0.f) { sum += v; cnt++; } }
+        off = cnt ? sum / (float)cnt : 0.f;
+    } else {
+        off = a.offsets[a.cam_no];
+    }
+    return a.time + off;
+}
+
+__global__ void __launch_bounds__(256) deform_frame_kernel(FrameArgs a)
+{
+    const int s = blockIdx.x;
+    if (!a.use_stage[s]) return;
+    __shared__ float sh_h[512];
+    float *fs = a.fs + (size_t)s * FS_STRIDE;
+    const float t = frame_time(a);
+    int rows[4], yrow[2]; float coefs[4], slope;
+    temporal_setup(a, s, t, rows, coefs, slope, yrow);
+    const int TD = a.TD;
+    for (int j = threadIdx.x; j < TD; j += blockDim.x) {
+        float r0 = a.table[(size_t)rows[0] * TD + j], r1 = a.table[(size_t)rows[1] * TD + j];
+        float r2 = a.table[(size_t)rows[2] * TD + j], r3 = a.table[(size_t)rows[3] * TD + j];
+        float h = coefs[0] * r0 + coefs[1] * r1 + coefs[2] * r2 + coefs[3] * r3;
+        // d h / d t = slope * (resized_row(y1) - resized_row(y0))
+        float rowA, rowB;
+        {
+            const int n = a.n_rows[s];
+            const float scale = n > 1 ? (float)(a.max_emb - 1) / (float)(n - 1) : 0.f;
+            float srcA = (float)yrow[0] * scale, srcB = (float)yrow[1] * scale;
+            float lA = srcA - floorf(srcA), lB = srcB - floorf(srcB);
+            rowA = (1.f - lA) * r0 + lA * r1;
+            rowB = (1.f - lB) * r2 + lB * r3;
+        }
+        fs[j] = h;
+        fs[TD + j] = slope * (rowB - rowA);
+        sh_h[j] = h;
+    }
+    if (threadIdx.x < 4) {
+        fs[2 * TD + threadIdx.x] = __int_as_float(rows[threadIdx.x]);
+        fs[2 * TD + 4 + threadIdx.x] = coefs[threadIdx.x];
+    }
+    __syncthreads();
+    const float *W1 = a.params[s] + a.W1_off;
+    const float *b1 = a.params[s] + a.b1_off;
+    const int ld = TD + a.E;
+    for (int o = threadIdx.x; o < a.W; o += blockDim.x) {
+        float acc = b1[o];
+        const float *w = W1 + (size_t)o * ld;
+        for (int j = 0; j < TD; j++) acc += w[j] * sh_h[j];
+        a.hb[s][o] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fragment builder: one thread per fragment element
+// ------------------------------------------------------------------------------------------------------------
+struct FragArgs {
+    int W, E, TD, n_sh, NT, ET, bwd;
+    int use_stage[2];
+    const float *params[2];
+    float *frag[2];
+    ParamLayout pl;
+    FragLayout fl;
+};
+
+__global__ void __launch_bounds__(256) deform_frag_kernel(FragArgs a)
+{
+    const int s = blockIdx.y;
+    if (!a.use_stage[s]) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *p = a.params[s];
+    float *f = a.frag[s];
+    const int W = a.W, NT = a.NT, ET = a.ET, ld1 = a.TD + a.E;
+    const size_t nF1 = (size_t)W * a.E, nF2 = (size_t)NHEAD * W * W, nF3 = (size_t)NHEAD * OTMAX * 32 * W;
+    const size_t nB2 = (size_t)NHEAD * W, nB3 = (size_t)NHEAD * OTMAX * 32;
+    size_t i = idx;
+    auto split = [](size_t v, int &lane, int &kk) { lane = (int)(v & 63); kk = (int)((v >> 6) & 15); return v >> 10; };
+    if (i < nF1) {  // F1[nt][et][kk][lane]
+        int lane, kk; size_t r = split(i, lane, kk);
+        int et = (int)(r % ET), nt = (int)(r / ET);
+        f[a.fl.F1 + i] = p[a.pl.W1 + (size_t)(nt * 32 + (lane & 31)) * ld1 + a.TD + et * 32 + fslot(kk, lane >> 5)];
+        if (a.bwd) {  // F1T[et][nt][kk][lane] = W1[nt*32 + f][TD + et*32 + lane&31]
+            size_t j = (((size_t)et * NT + nt) * 16 + kk) * 64 + lane;
+            f[a.fl.F1T + j] = p[a.pl.W1 + (size_t)(nt * 32 + fslot(kk, lane >> 5)) * ld1 + a.TD + et * 32 + (lane & 31)];
+        }
+        return;
+    }
+    i -= nF1;
+    if (i < nF2) {  // F2[k][nt][kt][kk][lane]
+        int lane, kk; size_t r = split(i, lane, kk);
+        int kt = (int)(r % NT); r /= NT;
+        int nt = (int)(r % NT); int k = (int)(r / NT);
+        f[a.fl.F2 + i] = p[a.pl.W2[k] + (size_t)(nt * 32 + (lane & 31)) * W + kt * 32 + fslot(kk, lane >> 5)];
+        if (a.bwd)  // F2T[k][it=nt][ot=kt][kk][lane] = W2[kt*32 + f][nt*32 + lane&31]
+            f[a.fl.F2T + i] = p[a.pl.W2[k] + (size_t)(kt * 32 + fslot(kk, lane >> 5)) * W + nt * 32 + (lane & 31)];
+        return;
+    }
+    i -= nF2;
+    if (i < nF3) {  // F3[k][ot][kt][kk][lane]
+        int lane, kk; size_t r = split(i, lane, kk);
+        int kt = (int)(r % NT); r /= NT;
+        int ot = (int)(r % OTMAX); int k = (int)(r / OTMAX);
+        const int nk = head_nk(k, a.n_sh);
+        int row = ot * 32 + (lane & 31);
+        f[a.fl.F3 + i] = row < nk ? p[a.pl.W3[k] + (size_t)row * W + kt * 32 + fslot(kk, lane >> 5)] : 0.f;
+        if (a.bwd) {  // F3T[k][it=kt][ot][kk][lane] = W3[ot*32 + f][kt*32 + lane&31]
+            size_t j = ((((size_t)k * NT + kt) * OTMAX + ot) * 16 + kk) * 64 + lane;
+            int rowT = ot * 32 + fslot(kk, lane >> 5);
+            f[a.fl.F3T + j] = rowT < nk ? p[a.pl.W3[k] + (size_t)rowT * W + kt * 32 + (lane & 31)] : 0.f;
+        }
+        return;
+    }
+    i -= nF3;
+    if (i < nB2) { int k = (int)(i / W), o = (int)(i % W); f[a.fl.B2 + i] = p[a.pl.b2[k] + o]; return; }
+    i -= nB2;
+    if (i < nB3) {
+        int k = (int)(i / (OTMAX * 32)), o = (int)(i % (OTMAX * 32));
+        f[a.fl.B3 + i] = o < head_nk(k, a.n_sh) ? p[a.pl.b3[k] + o] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MFMA helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias, int tile, int h)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = bias[tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    return acc;
+}
+// acc += sum over KT k-tiles of Wfrag[kt][kk] (x) x[kt][kk]
+template <int KT>
+__device__ __forceinline__ f32x16 gemm_tile(const float *__restrict__ frag, const float (&x)[KT][16], f32x16 acc, int lane)
+{
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[(kt * 16 + kk) * 64 + lane], x[kt][kk], acc, 0, 0, 0);
+    return acc;
+}
+
+// the lane's 16 embedding features in k-slot order: 4 float4 at offsets 4h + 8q
+__device__ __forceinline__ void load_emb_slots(const float *__restrict__ emb, int E, int g, int et, int h, float (&eb)[16])
+{
+    const float4 *row = reinterpret_cast<const float4 *>(emb + (size_t)g * E + et * 32 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float4 v = row[2 * q];
+        eb[4 * q] = v.x; eb[4 * q + 1] = v.y; eb[4 * q + 2] = v.z; eb[4 * q + 3] = v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward: one wave per strip of 32 Gaussians, both stages, five heads, register resident
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256) deform_forward_kernel(DeformDev d)
+{
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nstrips = (d.P + 31) / 32;
+    const int shw = 3 * d.n_sh;
+    for (int strip = wave; strip < nstrips; strip += nwaves) {
+        const int g_raw = strip * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        // current values (updated stage by stage)
+        float cx[3], cs[3], cr[4], co, csh[24];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { cx[i] = d.xyz[(size_t)g * 3 + i]; cs[i] = d.scales[(size_t)g * 3 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) cr[i] = d.rot[(size_t)g * 4 + i];
+        co = d.opacity[g];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {  // chunks: tile c>>2, q = c&3 -> features (c>>2)*32 + 8q + 4h
+            const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+            csh[4 * c] = v.x; csh[4 * c + 1] = v.y; csh[4 * c + 2] = v.z; csh[4 * c + 3] = v.w;
+        }
+        for (int s = 0; s < 2; s++) {
+            if (d.use_stage[s]) {
+                const float *fr = d.frag[s];
+                float a[NT][16];
+                {   // trunk: hid = hb + W1[:, TD:] emb ; a = relu(hid)
+                    f32x16 acc[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) acc[nt] = bias_acc(fr + d.fl.HB, nt, h);
+                    for (int et = 0; et < d.ET; et++) {
+                        float eb[1][16];
+                        load_emb_slots(d.emb, d.E, g, et, h, eb[0]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++)
+                            acc[nt] = gemm_tile<1>(fr + d.fl.F1 + ((size_t)nt * d.ET + et) * 1024, eb, acc[nt], lane);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[nt][r], 0.f);
+                }
+                for (int k = 0; k < NHEAD; k++) {
+                    if (!d.enabled[k]) continue;
+                    float z[NT][16];
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                        acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
+#pragma unroll
+                        for (int r = 0; r < 16; r++) z[nt][r] = fmaxf(acc[r], 0.f);
+                    }
+                    const float hc = d.hc[k];
+                    for (int ot = 0; ot < d.ot[k]; ot++) {
+                        f32x16 y = bias_acc(fr + d.fl.B3 + (size_t)k * OTMAX * 32, ot, h);
+                        y = gemm_tile<NT>(fr + d.fl.F3 + (((size_t)k * OTMAX + ot) * NT) * 1024, z, y, lane);
+                        if (k == 0) { if (h == 0) { cx[0] += y[0] * hc; cx[1] += y[1] * hc; cx[2] += y[2] * hc; } }
+                        else if (k == 1) { if (h == 0) { cs[0] += y[0] * hc; cs[1] += y[1] * hc; cs[2] += y[2] * hc; } }
+                        else if (k == 2) { if (h == 0) { cr[0] += y[0] * hc; cr[1] += y[1] * hc; cr[2] += y[2] * hc; cr[3] += y[3] * hc; } }
+                        else if (k == 3) { if (h == 0) co += y[0] * hc; }
+                        else {
+                            if (ot == 0) {
+#pragma unroll
+                                for (int r = 0; r < 16; r++) csh[r] += y[r] * hc;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 8; r++) csh[16 + r] += y[r] * hc;
+                            }
+                        }
+                    }
+                }
+            }
+            // write: after the coarse stage -> sub_*, after the fine stage -> out_*
+            float *const *dst = (s == 0) ? d.sub : d.out;
+            if (gvalid && dst[0]) {
+                if (h == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { dst[0][(size_t)g * 3 + i] = cx[i]; dst[1][(size_t)g * 3 + i] = cs[i]; }
+                    *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    dst[3][g] = co;
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
+                    if (feat < shw)
+                        *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
+                            make_float4(csh[4 * c], csh[4 * c + 1], csh[4 * c + 2], csh[4 * c + 3]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, input-gradient part: recompute, back-propagate through the heads and the trunk, store the matrices the
+// weight-gradient reduction needs, write dL/d embedding
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_tile_rows(float *__restrict__ M, int ld, int g, int nt, int h, const float (&v)[16])
+{
+    float4 *row = reinterpret_cast<float4 *>(M + (size_t)g * ld + nt * 32 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; q++) row[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) deform_dgrad_kernel(DeformDev d)
+{
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nstrips = (d.P + 31) / 32;
+    const int shw = 3 * d.n_sh;
+    const bool both = d.use_stage[0] && d.use_stage[1];
+    for (int strip = wave; strip < nstrips; strip += nwaves) {
+        const int g_raw = strip * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        float eb[1][16];
+        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);  // ET == 1 in the backward (checked on the host)
+        f32x16 ge;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ge[r] = 0.f;
+        for (int s = 0; s < 2; s++) {
+            if (!d.use_stage[s]) continue;
+            const float *fr = d.frag[s];
+            // gradient reaching this stage's head outputs: fine stage (or a lone stage) sees dL/d out; the coarse
+            // stage sees dL/d out + dL/d sub (out = sub + coef * delta_f)
+            const bool add_sub = (s == 0);
+            const bool add_out = (s == 1) || both || !d.use_stage[1];
+            float a[NT][16];
+            {
+                f32x16 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    acc[nt] = bias_acc(fr + d.fl.HB, nt, h);
+                    acc[nt] = gemm_tile<1>(fr + d.fl.F1 + (size_t)nt * 1024, eb, acc[nt], lane);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[nt][r], 0.f);
+                    if (gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
+                }
+            }
+            f32x16 ga[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
+            for (int k = 0; k < NHEAD; k++) {
+                if (!d.enabled[k]) continue;
+                float z[NT][16];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                    acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[nt][r] = fmaxf(acc[r], 0.f);
+                    if (gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[nt]);
+                }
+                // B operand of the head-output backward: gy[ot][kk] = hc * g_head[g][ot*32 + f(kk,h)]
+                const float hc = d.hc[k];
+                const int nk = d.nk[k];
+                float gy[OTMAX][16];
+#pragma unroll
+                for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
+                if (k < 4) {
+                    if (h == 0) {
+                        for (int j = 0; j < nk; j++) {  // features 0..nk-1 are k-slots kk = j of half 0
+                            float v = 0.f;
+                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
+                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
+                            gy[0][j] = v * hc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
+                        float4 v = make_float4(0, 0, 0, 0);
+                        if (feat < shw) {
+                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        }
+                        const int ot = c >> 2, kk0 = 4 * (c & 3);
+                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                    }
+                }
+                // g_z = (W3^T g_y) masked by z > 0 ; stored ; g_a += W2^T g_z
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    for (int ot = 0; ot < d.ot[k]; ot++) {
+                        const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX + ot) * 16) * 64;
+#pragma unroll
+                        for (int kk = 0; kk < 16; kk++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], ot == 0 ? gy[0][kk] : gy[1][kk], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[nt][r] = z[nt][r] > 0.f ? acc[r] : 0.f;
+                    if (gvalid) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[nt]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    ga[nt] = gemm_tile<NT>(fr + d.fl.F2T + (((size_t)k * NT + nt) * NT) * 1024, z, ga[nt], lane);
+            }
+            // g_hid = g_a masked by hid > 0 ; stored ; g_emb += W1[:, TD:]^T g_hid
+            float gh[NT][16];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) gh[nt][r] = a[nt][r] > 0.f ? ga[nt][r] : 0.f;
+                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh[nt]);
+            }
+            ge = gemm_tile<NT>(fr + d.fl.F1T, gh, ge, lane);
+        }
+        if (gvalid) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = ge[r];
+            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, weight-gradient part: dW[m][n] += sum_p G[p][m] * X[p][n], db[m] += sum_p G[p][m], split over p
+// ------------------------------------------------------------------------------------------------------------
+struct WgradJob {
+    const float *G; int ldg; int M; float gscale; const float *G2;  // G2: optional second addend (dL/d sub)
+    const float *X; int ldx; int N;
+    float *dW; int ldd; float *db;
+};
+constexpr int MAXJOBS = 24;
+struct WgradArgs {
+    int P, njobs, ksplit, chunk;
+    int tile_begin[MAXJOBS + 1];  // prefix sum of (m-tiles * n-tiles) per job
+    WgradJob job[MAXJOBS];
+};
+
+__global__ void __launch_bounds__(64) deform_wgrad_kernel(WgradArgs a)
+{
+    const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
+    const int tile = blockIdx.x, ks = blockIdx.y;
+    int j = 0;
+    while (j + 1 < a.njobs && tile >= a.tile_begin[j + 1]) j++;
+    const WgradJob &J = a.job[j];
+    const int ntn = (J.N + 31) / 32;
+    const int lt = tile - a.tile_begin[j];
+    const int mt = lt / ntn, nt = lt % ntn;
+    const int m = mt * 32 + c, n = nt * 32 + c;
+    const bool mok = m < J.M, nok = n < J.N;
+    const int p0 = ks * a.chunk, p1 = min(a.P, p0 + a.chunk);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float bsum = 0.f;
+    for (int pb = p0; pb < p1; pb += 8) {  // wave-uniform trip count: 8 rows = 4 MFMA k-steps of 2
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pp = pb + h + 2 * u;
+            const bool ok = pp < p1;
+            float gval = 0.f;
+            if (ok && mok) { gval = J.G ? J.G[(size_t)pp * J.ldg + m] : 0.f; if (J.G2) gval += J.G2[(size_t)pp * J.ldg + m]; gval *= J.gscale; }
+            av[u] = gval;
+            bv[u] = (ok && nok) ? J.X[(size_t)pp * J.ldx + n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+            bsum += av[u];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int mi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (mi < J.M && nok) atomicAdd(J.dW + (size_t)mi * J.ldd + n, acc[r]);
+    }
+    if (J.db && nt == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && mok) atomicAdd(J.db + m, bsum);
+    }
+}
+
+// frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
+struct FrameBwdArgs {
+    int W, E, TD, max_emb, num_offsets, cam_no;
+    int use_stage[2];
+    const float *params[2];
+    float *gparams[2];
+    size_t W1_off, b1_off;
+    const float *fs, *offsets;
+    float *g_table, *g_offsets;
+};
+__global__ void __launch_bounds__(256) deform_frame_bwd_kernel(FrameBwdArgs a)
+{
+    __shared__ float s_gt[32];
+    const int TD = a.TD, ld = TD + a.E;
+    float gt_local = 0.f;
+    for (int s = 0; s < 2; s++) {
+        if (!a.use_stage[s]) continue;
+        const float *fs = a.fs + (size_t)s * FS_STRIDE;
+        const float *W1 = a.params[s] + a.W1_off;
+        float *dW1 = a.gparams[s] + a.W1_off;
+        const float *ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
+        int rows[4]; float coefs[4];
+        for (int q = 0; q < 4; q++) { rows[q] = __float_as_int(fs[2 * TD + q]); coefs[q] = fs[2 * TD + 4 + q]; }
+        for (int j = threadIdx.x; j < TD; j += blockDim.x) {
+            const float hj = fs[j];
+            float gh = 0.f;
+            for (int o = 0; o < a.W; o++) {
+                const float gb = ghb[o];
+                dW1[(size_t)o * ld + j] = gb * hj;
+                gh += W1[(size_t)o * ld + j] * gb;
+            }
+            for (int q = 0; q < 4; q++) atomicAdd(a.g_table + (size_t)rows[q] * TD + j, coefs[q] * gh);
+            gt_local += gh * fs[TD + j];
+        }
+    }
+    // block reduction of dL/dt
+    for (int off = 32; off >= 1; off >>= 1) gt_local += __shfl_xor(gt_local, off);
+    if ((threadIdx.x & 63) == 0) s_gt[threadIdx.x >> 6] = gt_local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float gt = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) gt += s_gt[w];
+        if (a.cam_no >= 0) {
+            a.g_offsets[a.cam_no] = gt;
+        } else {
+            int cnt = 0;
+            for (int i = 0; i < a.num_offsets; i++) cnt += (a.offsets[i] != 0.f);
+            for (int i = 0; i < a.num_offsets; i++)
+                if (a.offsets[i] != 0.f) a.g_offsets[i] = gt / (float)cnt;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static bool validate(const ed3dgs_deform_cfg *c, const char *who)
+{
+    if (!c) { set_error(std::string(who) + ": null cfg"); return false; }
+    if (c->P < 0) { set_error(std::string(who) + ": bad P"); return false; }
+    if (!(c->W == 32 || c->W == 64 || c->W == 128 || c->W == 256)) { set_error(std::string(who) + ": net_width must be 32, 64, 128 or 256"); return false; }
+    if (c->D > 1) { set_error(std::string(who) + ": defor_depth > 1 is not supported by the fused MI355X path"); return false; }
+    if (c->E <= 0 || c->E % 32) { set_error(std::string(who) + ": gaussian_embedding_dim must be a multiple of 32"); return false; }
+    if (c->TD <= 0 || c->TD > 448) { set_error(std::string(who) + ": temporal_embedding_dim must be in [1, 448]"); return false; }
+    if (c->n_sh <= 0 || 3 * c->n_sh > 64 || (3 * c->n_sh) % 4) { set_error(std::string(who) + ": unsupported n_sh"); return false; }
+    for (int s = 0; s < 2; s++)
+        if (c->use_stage[s] && (c->n_rows[s] < 1 || c->max_embeddings < 1)) { set_error(std::string(who) + ": bad temporal row count"); return false; }
+    if (c->cam_no >= c->num_offsets) { set_error(std::string(who) + ": cam_no out of range"); return false; }
+    return true;
+}
+
+static void fill_dev(const ed3dgs_deform_cfg *c, DeformDev &d, bool bwd)
+{
+    d.P = c->P; d.W = c->W; d.E = c->E; d.TD = c->TD; d.n_sh = c->n_sh; d.NT = c->W / 32; d.ET = c->E / 32;
+    const int en[NHEAD] = {1, !c->no_ds, !c->no_dr, !c->no_do, !c->no_dc};
+    const float hc[NHEAD] = {c->coef, c->coef * c->coef_s, c->coef, c->coef * c->coef_o, c->coef_c};
+    for (int k = 0; k < NHEAD; k++) {
+        d.nk[k] = head_nk(k, c->n_sh); d.ot[k] = (d.nk[k] + 31) / 32; d.enabled[k] = en[k]; d.hc[k] = hc[k];
+    }
+    d.use_stage[0] = c->use_stage[0]; d.use_stage[1] = c->use_stage[1];
+    d.fl = frag_layout(c->W, c->E, bwd);
+}
+
+struct Workspace {
+    float *frag[2]; float *fs; float *A[2], *ZR[2], *GZ[2], *GHID[2];
+};
+static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace *ws)
+{
+    char *p = base;
+    FragLayout fl = frag_layout(c->W, c->E, bwd);
+    Workspace w;
+    for (int s = 0; s < 2; s++) obtain(p, w.frag[s], fl.total, 256);
+    obtain(p, w.fs, 2 * FS_STRIDE, 256);
+    if (bwd) {
+        const size_t PW = (size_t)(c->P > 0 ? c->P : 0) * c->W;
+        for (int s = 0; s < 2; s++) {
+            obtain(p, w.A[s], PW, 256); obtain(p, w.ZR[s], NHEAD * PW, 256);
+            obtain(p, w.GZ[s], NHEAD * PW, 256); obtain(p, w.GHID[s], PW, 256);
+        }
+    }
+    if (ws) *ws = w;
+    return (size_t)(p - base) + 256;
+}
+
+static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
+                     const Workspace &w, bool bwd, hipStream_t s)
+{
+    ParamLayout pl = param_layout(c->W, c->TD, c->E, c->n_sh);
+    FragLayout fl = frag_layout(c->W, c->E, bwd);
+    FragArgs fa;
+    fa.W = c->W; fa.E = c->E; fa.TD = c->TD; fa.n_sh = c->n_sh; fa.NT = c->W / 32; fa.ET = c->E / 32; fa.bwd = bwd;
+    fa.pl = pl; fa.fl = fl;
+    FrameArgs fr;
+    fr.W = c->W; fr.E = c->E; fr.TD = c->TD; fr.max_emb = c->max_embeddings; fr.num_offsets = c->num_offsets;
+    fr.cam_no = c->cam_no; fr.time = c->time; fr.table = table; fr.offsets = offsets; fr.W1_off = pl.W1; fr.b1_off = pl.b1;
+    fr.fs = w.fs;
+    for (int st = 0; st < 2; st++) {
+        fa.use_stage[st] = fr.use_stage[st] = c->use_stage[st];
+        fa.params[st] = fr.params[st] = params[st];
+        fa.frag[st] = w.frag[st];
+        fr.n_rows[st] = c->n_rows[st];
+        fr.hb[st] = w.frag[st] + fl.HB;
+    }
+    const size_t nelem = (size_t)c->W * c->E + (size_t)NHEAD * c->W * c->W + (size_t)NHEAD * OTMAX * 32 * c->W +
+                         (size_t)NHEAD * c->W + (size_t)NHEAD * OTMAX * 32;
+    hipLaunchKernelGGL(deform_frag_kernel, dim3((unsigned)((nelem + 255) / 256), 2), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL(deform_frame_kernel, dim3(2), dim3(256), 0, s, fr);
+    return check_hip(hipGetLastError(), "deform prep");
+}
+
+template <typename F>
+static void dispatch_nt(int NT, F f)
+{
+    switch (NT) { case 1: f(std::integral_constant<int, 1>()); break; case 2: f(std::integral_constant<int, 2>()); break;
+                  case 4: f(std::integral_constant<int, 4>()); break; default: f(std::integral_constant<int, 8>()); break; }
+}
+
+}  // namespace ed3
+
 using namespace ed3;
+
 extern "C" {
-size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *) { return 0; }
-size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *, int) { return 0; }
-int ed3dgs_deform_forward(const ed3dgs_deform_cfg *, const float *, const float *const[2], const float *, const float *,
-                          const float *, const float *, const float *, const float *, float *, float *, float *, float *,
-                          float *, float *, float *, float *, float *, float *, char *, size_t, void *)
+
+size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *cfg)
 {
-    set_error("ed3dgs_deform_forward: not built yet");
-    return ED3DGS_ERR_INVALID;
+    if (!cfg) return 0;
+    return param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh).total;
 }
-int ed3dgs_deform_backward(const ed3dgs_deform_cfg *, const float *, const float *const[2], const float *, const float *,
-                           const float *, const float *, const float *, const float *, const float *, const float *,
-                           const float *, const float *, const float *, float *const[2], float *, float *, const char *,
-                           size_t, char *, size_t, void *)
+
+size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backward)
 {
-    set_error("ed3dgs_deform_backward: not built yet");
-    return ED3DGS_ERR_INVALID;
+    if (!cfg) return 0;
+    return carve(cfg, for_backward != 0, nullptr, nullptr);
 }
+
+int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                          const float *const params[2], const float *embedding, const float *xyz, const float *scales,
+                          const float *rot, const float *opacity, const float *sh, float *out_xyz, float *out_scales,
+                          float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
+                          float *sub_rot, float *sub_opacity, float *sub_sh, char *workspace, size_t workspace_bytes,
+                          void *stream)
+{
+    if (!validate(cfg, "ed3dgs_deform_forward")) return ED3DGS_ERR_INVALID;
+    if (cfg->P == 0) return 0;
+    if (!table || !offsets || !embedding || !xyz || !scales || !rot || !opacity || !sh || !out_xyz || !out_scales ||
+        !out_rot || !out_opacity || !out_sh || !workspace) { set_error("ed3dgs_deform_forward: null pointer"); return ED3DGS_ERR_INVALID; }
+    for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && !params[s]) { set_error("ed3dgs_deform_forward: null params"); return ED3DGS_ERR_INVALID; }
+    const bool have_sub = sub_xyz && sub_scales && sub_rot && sub_opacity && sub_sh;
+    if (!have_sub && (sub_xyz || sub_scales || sub_rot || sub_opacity || sub_sh)) { set_error("ed3dgs_deform_forward: sub_* must be all set or all NULL"); return ED3DGS_ERR_INVALID; }
+    if (workspace_bytes < carve(cfg, false, nullptr, nullptr)) { set_error("ed3dgs_deform_forward: workspace too small"); return ED3DGS_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w;
+    carve(cfg, false, workspace, &w);
+    if (!run_prep(cfg, table, offsets, params, w, false, s)) return ED3DGS_ERR_HIP;
+    DeformDev d;
+    std::memset(&d, 0, sizeof d);
+    fill_dev(cfg, d, false);
+    d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
+    d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh;
+    float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
+    float *subs[5] = {sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh};
+    for (int i = 0; i < 5; i++) { d.out[i] = outs[i]; d.sub[i] = have_sub ? subs[i] : nullptr; }
+    const int nstrips = (cfg->P + 31) / 32;
+    const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
+    dispatch_nt(d.NT, [&](auto nt) {
+        hipLaunchKernelGGL((deform_forward_kernel<decltype(nt)::value>), dim3(blocks), dim3(256), 0, s, d);
+    });
+    if (!check_hip(hipGetLastError(), "deform forward")) return ED3DGS_ERR_HIP;
+    return 0;
 }
+
+int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                           const float *const params[2], const float *embedding, const float *g_xyz,
+                           const float *g_scales, const float *g_rot, const float *g_opacity, const float *g_sh,
+                           const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
+                           const float *gs_sh, float *const gparams[2], float *g_table, float *g_offsets,
+                           float *g_embedding, char *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!validate(cfg, "ed3dgs_deform_backward")) return ED3DGS_ERR_INVALID;
+    if (cfg->E != 32) { set_error("ed3dgs_deform_backward: gaussian_embedding_dim must be 32"); return ED3DGS_ERR_INVALID; }
+    if (!table || !offsets || !g_table || !g_offsets || !workspace) { set_error("ed3dgs_deform_backward: null pointer"); return ED3DGS_ERR_INVALID; }
+    for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && (!params[s] || !gparams[s])) { set_error("ed3dgs_deform_backward: null params"); return ED3DGS_ERR_INVALID; }
+    if (workspace_bytes < carve(cfg, true, nullptr, nullptr)) { set_error("ed3dgs_deform_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    const ParamLayout pl = param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh);
+    if (!check_hip(hipMemsetAsync(g_table, 0, (size_t)cfg->max_embeddings * cfg->TD * sizeof(float), s), "memset g_table")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipMemsetAsync(g_offsets, 0, (size_t)cfg->num_offsets * sizeof(float), s), "memset g_offsets")) return ED3DGS_ERR_HIP;
+    for (int st = 0; st < 2; st++)
+        if (cfg->use_stage[st] && !check_hip(hipMemsetAsync(gparams[st], 0, pl.total * sizeof(float), s), "memset gparams")) return ED3DGS_ERR_HIP;
+    if (cfg->P == 0) return 0;
+    if (!embedding || !g_embedding) { set_error("ed3dgs_deform_backward: null embedding pointer"); return ED3DGS_ERR_INVALID; }
+    Workspace w;
+    carve(cfg, true, workspace, &w);
+    if (!run_prep(cfg, table, offsets, params, w, true, s)) return ED3DGS_ERR_HIP;
+    DeformDev d;
+    std::memset(&d, 0, sizeof d);
+    fill_dev(cfg, d, true);
+    d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
+    d.emb = embedding;
+    const float *gg[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
+    const float *gsub[5] = {gs_xyz, gs_scales, gs_rot, gs_opacity, gs_sh};
+    for (int i = 0; i < 5; i++) { d.g[i] = gg[i]; d.gs[i] = gsub[i]; }
+    for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.GZ[st] = w.GZ[st]; d.GHID[st] = w.GHID[st]; }
+    d.g_emb = g_embedding;
+    if (!cfg->use_stage[0] && !cfg->use_stage[1]) {
+        if (!check_hip(hipMemsetAsync(g_embedding, 0, (size_t)cfg->P * cfg->E * sizeof(float), s), "memset g_emb")) return ED3DGS_ERR_HIP;
+        return 0;
+    }
+    const int nstrips = (cfg->P + 31) / 32;
+    const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
+    dispatch_nt(d.NT, [&](auto nt) {
+        hipLaunchKernelGGL((deform_dgrad_kernel<decltype(nt)::value>), dim3(blocks), dim3(256), 0, s, d);
+    });
+    if (!check_hip(hipGetLastError(), "deform dgrad")) return ED3DGS_ERR_HIP;
+
+    // weight gradients
+    WgradArgs wa;
+    std::memset(&wa, 0, sizeof wa);
+    wa.P = cfg->P;
+    int nj = 0, tiles = 0;
+    const bool both = cfg->use_stage[0] && cfg->use_stage[1];
+    for (int st = 0; st < 2; st++) {
+        if (!cfg->use_stage[st]) continue;
+        const bool add_sub = (st == 0), add_out = (st == 1) || both || !cfg->use_stage[1];
+        const size_t PW = (size_t)cfg->P * cfg->W;
+        for (int k = 0; k < NHEAD; k++) {
+            if (!d.enabled[k]) continue;
+            const float *G = add_out ? gg[k] : nullptr, *G2 = add_sub ? gsub[k] : nullptr;
+            if (G || G2) {  // dW3 / db3 from the upstream gradient of the head's output
+                WgradJob &J = wa.job[nj];
+                if (!G) { G = G2; G2 = nullptr; }
+                J.G = G; J.G2 = G2; J.ldg = d.nk[k]; J.M = d.nk[k]; J.gscale = d.hc[k];
+                J.X = w.ZR[st] + k * PW; J.ldx = cfg->W; J.N = cfg->W;
+                J.dW = gparams[st] + pl.W3[k]; J.ldd = cfg->W; J.db = gparams[st] + pl.b3[k];
+                wa.tile_begin[nj] = tiles; tiles += ((J.M + 31) / 32) * ((J.N + 31) / 32); nj++;
+            }
+            {   // dW2 / db2
+                WgradJob &J = wa.job[nj];
+                J.G = w.GZ[st] + k * PW; J.G2 = nullptr; J.ldg = cfg->W; J.M = cfg->W; J.gscale = 1.f;
+                J.X = w.A[st]; J.ldx = cfg->W; J.N = cfg->W;
+                J.dW = gparams[st] + pl.W2[k]; J.ldd = cfg->W; J.db = gparams[st] + pl.b2[k];
+                wa.tile_begin[nj] = tiles; tiles += ((J.M + 31) / 32) * ((J.N + 31) / 32); nj++;
+            }
+        }
+        {   // dW1[:, TD:] and db1 (= g_hb)
+            WgradJob &J = wa.job[nj];
+            J.G = w.GHID[st]; J.G2 = nullptr; J.ldg = cfg->W; J.M = cfg->W; J.gscale = 1.f;
+            J.X = embedding; J.ldx = cfg->E; J.N = cfg->E;
+            J.dW = gparams[st] + pl.W1 + cfg->TD; J.ldd = cfg->TD + cfg->E; J.db = gparams[st] + pl.b1;
+            wa.tile_begin[nj] = tiles; tiles += ((J.M + 31) / 32) * ((J.N + 31) / 32); nj++;
+        }
+    }
+    wa.njobs = nj; wa.tile_begin[nj] = tiles;
+    int ksplit = std::max(1, std::min(256, (256 * 16 + tiles - 1) / std::max(tiles, 1)));
+    int chunk = ((cfg->P + ksplit - 1) / ksplit + 7) & ~7;
+    if (chunk < 8) chunk = 8;
+    ksplit = (cfg->P + chunk - 1) / chunk;
+    wa.ksplit = ksplit; wa.chunk = chunk;
+    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(tiles, ksplit), dim3(64), 0, s, wa);
+    if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
+
+    FrameBwdArgs fb;
+    fb.W = cfg->W; fb.E = cfg->E; fb.TD = cfg->TD; fb.max_emb = cfg->max_embeddings; fb.num_offsets = cfg->num_offsets;
+    fb.cam_no = cfg->cam_no; fb.W1_off = pl.W1; fb.b1_off = pl.b1; fb.fs = w.fs; fb.offsets = offsets;
+    fb.g_table = g_table; fb.g_offsets = g_offsets;
+    for (int st = 0; st < 2; st++) { fb.use_stage[st] = cfg->use_stage[st]; fb.params[st] = params[st]; fb.gparams[st] = gparams[st]; }
+    hipLaunchKernelGGL(deform_frame_bwd_kernel, dim3(1), dim3(256), 0, s, fb);
+    if (!check_hip(hipGetLastError(), "deform frame backward")) return ED3DGS_ERR_HIP;
+    return 0;
+}
+
+}  // extern "C"

@@ -12,10 +12,12 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class DeformCfg(C.Structure):
+    """ed3dgs_deform_cfg of include/ed3dgs.h (field order must match)."""
     _fields_ = [("P", C.c_int), ("W", C.c_int), ("D", C.c_int), ("E", C.c_int), ("TD", C.c_int), ("n_sh", C.c_int),
-                ("use_stage", C.c_int * 2), ("no_ds", C.c_int), ("no_dr", C.c_int), ("no_do", C.c_int),
+                ("max_embeddings", C.c_int), ("num_offsets", C.c_int), ("use_stage", C.c_int * 2),
+                ("n_rows", C.c_int * 2), ("no_ds", C.c_int), ("no_dr", C.c_int), ("no_do", C.c_int),
                 ("no_dc", C.c_int), ("coef", C.c_float), ("coef_c", C.c_float), ("coef_o", C.c_float),
-                ("coef_s", C.c_float)]
+                ("coef_s", C.c_float), ("time", C.c_float), ("cam_no", C.c_int)]
 
 
 class StateView(C.Structure):

@@ -1,0 +1,189 @@
+"""scene.deformation -- MI355X-native drop-in for the reference's deform_network (scene/deformation.py:15-148).
+
+Same constructor, same parameter / state-dict names (`weight`, `offsets`, `feature_out_{c,f}.0.*`,
+`{pos,scales,rotations,opacity,rgb}_deform_{c,f}.{1,3}.*`, so `deformation.pth` loads unchanged,
+scene/gaussian_model.py:250-258) and the same `forward` signature / return structure (:108-141).  The arithmetic runs
+in the fused HIP kernels of csrc/deform.hip through the C ABI (include/ed3dgs.h); torch only owns the parameters,
+allocates outputs and links the call into autograd.  There is no CPU or eager fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ed3dgs_amd import _lib
+
+HEADS = ("pos", "scales", "rotations", "opacity", "rgb")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _c32(t):
+    return None if t is None else t.detach().contiguous().float()
+
+
+class _DeformFn(torch.autograd.Function):
+    """forward/backward of both stages as C-ABI calls.  Differentiable inputs: temporal table, offsets, the two packed
+    parameter blocks, Gaussian embedding, and the five base tensors."""
+
+    @staticmethod
+    def forward(ctx, cfgd, want_sub, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh):
+        L = _lib.lib()
+        cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
+        cfg.use_stage[0], cfg.use_stage[1] = cfgd["use_stage"]
+        cfg.n_rows[0], cfg.n_rows[1] = cfgd["n_rows"]
+        dev = xyz.device
+        if not xyz.is_cuda:
+            raise RuntimeError("deform_network: tensors must be on the GPU (the MI355X path has no CPU fallback)")
+        ins = [_c32(t) for t in (table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh)]
+        table_, offsets_, fc, ff, emb_, xyz_, sc_, rot_, op_, sh_ = ins
+        outs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_, sh_)]
+        subs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_, sh_)] if want_sub else [None] * 5
+        ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(0))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
+        rc = L.ed3dgs_deform_forward(
+            C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
+            _ptr(sh_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc < 0:
+            raise RuntimeError(_lib.last_error())
+        ctx.cfgd = cfgd
+        ctx.want_sub = want_sub
+        ctx.save_for_backward(table_, offsets_, fc, ff, emb_)
+        ctx.shapes = [t.shape for t in (table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh)]
+        if want_sub:
+            return tuple(outs) + tuple(subs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gr):
+        L = _lib.lib()
+        cfgd = ctx.cfgd
+        cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
+        cfg.use_stage[0], cfg.use_stage[1] = cfgd["use_stage"]
+        cfg.n_rows[0], cfg.n_rows[1] = cfgd["n_rows"]
+        table_, offsets_, fc, ff, emb_ = ctx.saved_tensors
+        dev = emb_.device
+        g_out = [_c32(g) for g in gr[:5]]
+        g_sub = [_c32(g) for g in gr[5:10]] if ctx.want_sub else [None] * 5
+        gfc = torch.empty_like(fc)
+        gff = torch.empty_like(ff)
+        g_table = torch.empty_like(table_)
+        g_off = torch.empty_like(offsets_)
+        g_emb = torch.empty_like(emb_)
+        ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
+        gparams = (C.c_void_p * 2)(gfc.data_ptr() if cfgd["use_stage"][0] else None, gff.data_ptr() if cfgd["use_stage"][1] else None)
+        rc = L.ed3dgs_deform_backward(
+            C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), *[_ptr(g) for g in g_out],
+            *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(ws),
+            C.c_size_t(ws_bytes), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc < 0:
+            raise RuntimeError(_lib.last_error())
+        if not cfgd["use_stage"][0]:
+            gfc.zero_()
+        if not cfgd["use_stage"][1]:
+            gff.zero_()
+        base = []
+        for i in range(5):  # identity paths: out = base + ..., sub = base + ...
+            a, b = gr[i], (gr[5 + i] if ctx.want_sub else None)
+            g = a if b is None else (b if a is None else a + b)
+            base.append(None if g is None else g.reshape(ctx.shapes[5 + i]))
+        sh = ctx.shapes
+        return (None, None, g_table.reshape(sh[0]), g_off.reshape(sh[1]), gfc.reshape(sh[2]), gff.reshape(sh[3]),
+                g_emb.reshape(sh[4]), *base)
+
+
+class deform_network(nn.Module):
+    def __init__(self, D=8, W=256, min_embeddings=30, max_embeddings=150, num_frames=300, num_cam=None, args=None):
+        super().__init__()
+        self.D = D
+        self.W = W
+        self.args = args
+        self.min_embeddings = min_embeddings
+        self.max_embeddings = max_embeddings
+        self.num_frames = num_frames
+        self.temporal_embedding_dim = args.temporal_embedding_dim
+        self.gaussian_embedding_dim = args.gaussian_embedding_dim
+        self.c2f_temporal_iter = args.c2f_temporal_iter
+        (self.feature_out_c, self.pos_deform_c, self.scales_deform_c, self.rotations_deform_c, self.opacity_deform_c,
+         self.rgb_deform_c) = self.create_net()
+        (self.feature_out_f, self.pos_deform_f, self.scales_deform_f, self.rotations_deform_f, self.opacity_deform_f,
+         self.rgb_deform_f) = self.create_net()
+        td = self.temporal_embedding_dim
+        if args.zero_temporal:
+            table = torch.zeros(max_embeddings, td)
+        else:
+            table = torch.normal(0., 0.01 / np.sqrt(td), size=(max_embeddings, td))
+        self.weight = nn.Parameter(table)
+        self.offsets = nn.Parameter(torch.zeros((30, 1)))  # per-camera time offsets (reference: hard-coded 30)
+
+    def create_net(self):
+        """Module layout of the reference (:38-51), kept so the state-dict keys are identical."""
+        W = self.W
+        trunk = [nn.Linear(self.temporal_embedding_dim + self.gaussian_embedding_dim, W)]
+        for _ in range(self.D - 1):
+            trunk += [nn.ReLU(), nn.Linear(W, W)]
+        head = lambda n: nn.Sequential(nn.ReLU(), nn.Linear(W, W), nn.ReLU(), nn.Linear(W, n))
+        return nn.Sequential(*trunk), head(3), head(3), head(4), head(1), head(3 * 16)
+
+    def int_lininterp(self, t, init_val, final_val, until):
+        return int(init_val + (final_val - init_val) * min(max(t, 0), until) / until)
+
+    def get_mlp_parameters(self):
+        return [p for n, p in self.named_parameters() if n != "offsets"]
+
+    # ---- helpers of the fused path ----
+    def _flat_stage(self, s):
+        mods = [getattr(self, f"feature_out_{s}")[0]]
+        parts = [mods[0].weight.reshape(-1), mods[0].bias]
+        for h in HEADS:
+            seq = getattr(self, f"{h}_deform_{s}")
+            parts += [seq[1].weight.reshape(-1), seq[1].bias, seq[3].weight.reshape(-1), seq[3].bias]
+        return torch.cat(parts)
+
+    def _row_counts(self, it, num_down_emb_c, num_down_emb_f):
+        """query_time (:72-80)"""
+        a = self.args
+
+        def c2f(nd):
+            if a.no_c2f_temporal_embedding:
+                return self.max_embeddings
+            return self.int_lininterp(it, nd, self.max_embeddings, self.c2f_temporal_iter)
+        n_c = num_down_emb_c if a.use_coarse_temporal_embedding else c2f(num_down_emb_c)
+        return n_c, c2f(num_down_emb_f)
+
+    def forward(self, point, scales=None, rotations=None, opacity=None, time_emb=None, cam_no=None, pc=None,
+                embeddings=None, sh_coefs=None, iter=None, num_down_emb_c=30, num_down_emb_f=30, want_extras=True):
+        a = self.args
+        if self.D > 1:
+            raise NotImplementedError("defor_depth > 1 is not supported by the fused MI355X deformation path")
+        pts, scales, rotations, opacity = point[:, :3], scales[:, :3], rotations[:, :4], opacity[:, :1]
+        orig = (pts, scales, rotations, opacity, sh_coefs)
+        emb = embeddings if pc is None else pc.get_embedding
+        # the reference reads only time_emb[0, 0] (:58); a Python float avoids the device read-back
+        time = float(time_emb) if not torch.is_tensor(time_emb) else float(time_emb.reshape(-1)[0])
+        use_anneal = a.use_anneal
+        coef = 1.0 if not use_anneal else float(np.clip(iter / 1000, 0, 1))
+        coef_x = 1.0 if not use_anneal else float(np.clip((iter - a.deform_from_iter) / 1000, 0, 1))
+        n_c, n_f = self._row_counts(iter, num_down_emb_c, num_down_emb_f)
+        cfgd = dict(P=pts.shape[0], W=self.W, D=self.D, E=self.gaussian_embedding_dim, TD=self.temporal_embedding_dim,
+                    n_sh=sh_coefs.shape[1], max_embeddings=self.max_embeddings, num_offsets=self.offsets.shape[0],
+                    use_stage=(int(not a.no_coarse_deform), int(not a.no_fine_deform)), n_rows=(int(n_c), int(n_f)),
+                    no_ds=int(a.no_ds), no_dr=int(a.no_dr), no_do=int(a.no_do), no_dc=int(a.no_dc), coef=coef,
+                    coef_c=coef_x, coef_o=coef_x, coef_s=coef_x, time=time, cam_no=-1 if cam_no is None else int(cam_no))
+        res = _DeformFn.apply(cfgd, bool(want_extras), self.weight, self.offsets, self._flat_stage("c"),
+                              self._flat_stage("f"), emb, pts, scales, rotations, opacity, sh_coefs)
+        final = res[:5]
+        sub = res[5:10] if want_extras else orig
+        return final[0], final[1], final[2], final[3], final[4], (tuple(sub), orig)
+
+
+def initialize_weights(m):
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight, gain=1)

@@ -127,56 +127,61 @@ int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geome
                           const char *binning_buffer, const char *image_buffer, ed3dgs_state_view *out);
 
 /* ---------------- deformation MLP (scene/deformation.py) ---------------- */
-/* Network description: W = hidden width, D = trunk depth (D<=1: single Linear), E = gaussian embedding dim (32),
- * TD = temporal embedding dim (256).  Parameter block layout (fp32, one per stage, `c` then `f`):
- * see ed3dgs_deform_param_count(). */
+/*
+ * deform_network.forward (scene/deformation.py:108-141) as fused launches: the per-frame temporal row
+ * (get_temporal_embed :53-67, time offset :112-117) is computed on the device from the table, and the per-Gaussian
+ * MLP (trunk Linear over [h_t | embedding], five heads Linear-ReLU-Linear, residual updates :90-106) runs on fp32
+ * MFMA with activations resident in registers.  W = net_width (multiple of 32, <= 256), E = gaussian embedding dim
+ * (multiple of 32), TD = temporal embedding dim, D = defor_depth (0 or 1: the trunk is one Linear; deeper trunks
+ * are rejected with ED3DGS_ERR_INVALID).
+ * Packed parameter block of one stage (fp32, state-dict order of scene/deformation.py:38-51):
+ *   feature_out.0.weight[W][TD+E], feature_out.0.bias[W],
+ *   for head in (pos, scales, rotations, opacity, rgb): {1.weight[W][W], 1.bias[W], 3.weight[n_k][W], 3.bias[n_k]},
+ *   n_k = 3, 3, 4, 1, 3*n_sh.
+ */
 typedef struct ed3dgs_deform_cfg {
-    int P;            /* Gaussians */
-    int W;            /* net_width */
-    int D;            /* defor_depth */
-    int E;            /* gaussian_embedding_dim */
-    int TD;           /* temporal_embedding_dim */
-    int n_sh;         /* SH coefficients per Gaussian the rgb head updates (16) */
-    int use_stage[2]; /* [0] coarse (!no_coarse_deform), [1] fine (!no_fine_deform) */
+    int P;               /* Gaussians */
+    int W, D, E, TD;     /* net_width, defor_depth, gaussian_embedding_dim, temporal_embedding_dim */
+    int n_sh;            /* SH coefficients per Gaussian the rgb head updates (16, :105) */
+    int max_embeddings;  /* rows of the temporal table */
+    int num_offsets;     /* rows of `offsets` (30, :36) */
+    int use_stage[2];    /* [0] coarse = !no_coarse_deform, [1] fine = !no_fine_deform */
+    int n_rows[2];       /* rows the table is resized to for the coarse / fine stage (query_time :72-80) */
     int no_ds, no_dr, no_do, no_dc;
-    float coef, coef_c, coef_o, coef_s; /* anneal scalars, scene/deformation.py:119-123 */
+    float coef, coef_c, coef_o, coef_s; /* anneal scalars (:119-123) */
+    float time;          /* camera time before the offset */
+    int cam_no;          /* index into offsets, or -1 for None (mean of the non-zero offsets) */
 } ed3dgs_deform_cfg;
 
-/* floats in one stage's packed parameter block:
- *  trunk0.weight[W][TD+E], trunk0.bias[W], (D-1) x { weight[W][W], bias[W] },
- *  5 heads (pos, scales, rotations, opacity, rgb) x { l1.weight[W][W], l1.bias[W], l2.weight[n_k][W], l2.bias[n_k] },
- *  n_k = 3,3,4,1,3*n_sh.  (state-dict order of scene/deformation.py:38-51) */
-size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *cfg);
+size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *cfg);              /* floats in one stage block */
 size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backward);
 
 /*
- * Forward: h_t[2][TD] = temporal embedding rows already resampled at time t for stage c / f (host-side lerp of the
- * 150x256 table, scene/deformation.py:53-67 -- 2 x 256 floats per frame); params[2] = packed stage blocks;
- * embedding[P][E]; base tensors xyz[P,3], scales[P,3], rot[P,4], opacity[P], sh[P,n_sh,3].
- * Outputs out_*: final values; sub_*: values after the coarse stage (the `extras[0]` tuple, :139-141); sub_* may be
- * NULL.  `saved` (workspace from ed3dgs_deform_workspace_bytes(cfg,0)) keeps what backward needs.
+ * Forward.  table[max_embeddings][TD], offsets[num_offsets], params[2] (coarse, fine; NULL if the stage is off),
+ * embedding[P][E], base tensors xyz[P,3], scales[P,3], rot[P,4], opacity[P], sh[P,n_sh,3].
+ * out_*: values after both stages; sub_*: values after the coarse stage (extras[0], :139-141), may be NULL.
  */
-int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *h_t, const float *const params[2],
-                          const float *embedding, const float *xyz, const float *scales, const float *rot,
-                          const float *opacity, const float *sh,
+int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                          const float *const params[2], const float *embedding, const float *xyz,
+                          const float *scales, const float *rot, const float *opacity, const float *sh,
                           float *out_xyz, float *out_scales, float *out_rot, float *out_opacity, float *out_sh,
                           float *sub_xyz, float *sub_scales, float *sub_rot, float *sub_opacity, float *sub_sh,
-                          char *saved, size_t saved_bytes, void *stream);
+                          char *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * Backward: g_* = dL/d(out_*) (NULL = zero), gs_* = dL/d(sub_*) (NULL = zero).
- * Writes dL/d(params) into gparams[2] (accumulates: caller zero-fills), dL/dh_t into g_h_t[2][TD] (accumulates),
- * dL/dembedding[P][E] (written).  Gradients w.r.t. the base tensors are g_* + gs_* (identity), left to the caller.
+ * Backward (stateless: recomputes the forward activations).  g_* = dL/d(out_*), gs_* = dL/d(sub_*); NULL = zero.
+ * Every output is fully written: gparams[2] (packed like params), g_table[max_embeddings][TD],
+ * g_offsets[num_offsets], g_embedding[P][E].  Gradients w.r.t. the base tensors are g_* + gs_* (identity paths)
+ * and are left to the caller.
  */
-int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *h_t, const float *const params[2],
-                           const float *embedding,
+int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                           const float *const params[2], const float *embedding,
                            const float *g_xyz, const float *g_scales, const float *g_rot, const float *g_opacity,
                            const float *g_sh,
                            const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
                            const float *gs_sh,
-                           float *const gparams[2], float *g_h_t, float *g_embedding,
-                           const char *saved, size_t saved_bytes, char *workspace, size_t workspace_bytes,
-                           void *stream);
+                           float *const gparams[2], float *g_table, float *g_offsets, float *g_embedding,
+                           char *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

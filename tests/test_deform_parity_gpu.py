@@ -1,0 +1,150 @@
+"""GPU parity of the fused HIP deformation network (scene/deformation.py drop-in) against
+  (1) the golden fixtures generated from the reference's own scene/deformation.py (values and autograd gradients),
+  (2) the PyTorch-CPU restatement (oracle/deformation_torch.py, itself pinned by the same fixtures) at larger sizes.
+Tolerance: 1e-4 relative L-inf (north_star), measured against each tensor's max magnitude."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "deform_*.npz")))
+TOL = 1e-4
+NAMES = ("xyz", "scales", "rot", "opacity", "sh")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+class _Args:
+    pass
+
+
+def _load(path):
+    z = np.load(path)
+    a = _Args()
+    for k in z.files:
+        if k.startswith("arg_"):
+            setattr(a, k[4:], z[k].item())
+    return z, a
+
+
+def _build(z, a, device="cuda"):
+    from scene.deformation import deform_network
+    net = deform_network(D=int(z["cfg_D"]), W=int(z["cfg_W"]), min_embeddings=int(z["cfg_min"]),
+                         max_embeddings=int(z["cfg_max"]), num_frames=300, args=a)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
+    net.load_state_dict(sd, strict=True)  # state-dict compatibility with the reference (deformation.pth)
+    return net.to(device)
+
+
+class _PC:
+    def __init__(self, e):
+        self.get_embedding = e
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64).reshape(a.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
+def test_golden_values_and_grads(path):
+    _need_gpu()
+    z, a = _load(path)
+    if int(z["cfg_D"]) > 1:
+        net = _build(z, a)
+        with pytest.raises(NotImplementedError):
+            net(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 4).cuda(), torch.zeros(4, 1).cuda(),
+                0.5, None, _PC(torch.zeros(4, 32).cuda()), None, torch.zeros(4, 16, 3).cuda(), iter=10)
+        return
+    net = _build(z, a)
+    leaf = lambda n: torch.from_numpy(z["in_" + n]).cuda().requires_grad_(True)
+    xyz, scales, rot, opacity, sh, emb = [leaf(n) for n in ("xyz", "scales", "rot", "opacity", "sh", "emb")]
+    cam = int(z["cfg_cam_no"]); cam = None if cam < 0 else cam
+    outs = net(xyz, scales, rot, opacity, float(z["cfg_time"]), cam, _PC(emb), None, sh, iter=int(z["cfg_iter"]),
+               num_down_emb_c=int(z["cfg_nde_c"]), num_down_emb_f=int(z["cfg_nde_f"]))
+    final, sub = outs[:5], outs[5][0]
+    errs = {}
+    for n, t in zip(NAMES, final):
+        errs["out_" + n] = rel(t.detach().cpu().numpy(), z["out_" + n])
+    for n, t in zip(NAMES, sub):
+        errs["sub_" + n] = rel(t.detach().cpu().numpy(), z["sub_" + n])
+    ws = [torch.from_numpy(z[f"lossw_{i}"]).cuda() for i in range(10)]
+    loss = sum((t * w.reshape(t.shape)).sum() for t, w in zip(list(final) + list(sub), ws))
+    loss.backward()
+    gerrs = {}
+    for name, p in net.named_parameters():
+        ref = z["gsd_" + name]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        got = torch.zeros_like(p) if p.grad is None else p.grad
+        if np.abs(ref).max() == 0:
+            assert float(got.abs().max()) < 1e-12, name
+            continue
+        gerrs[name] = rel(got.cpu().numpy(), ref)
+    for n, t in zip(("xyz", "scales", "rot", "opacity", "sh", "emb"), (xyz, scales, rot, opacity, sh, emb)):
+        gerrs["in_" + n] = rel(t.grad.cpu().numpy(), z["gin_" + n])
+    print(os.path.basename(path), "value max", max(errs.values()), "grad max", max(gerrs.values()),
+          "worst", max(gerrs, key=gerrs.get))
+    for k, v in {**errs, **gerrs}.items():
+        assert v <= TOL, (k, v)
+
+
+@pytest.mark.parametrize("P,W", [(5000, 128), (777, 64)])
+def test_against_torch_restatement(P, W):
+    _need_gpu()
+    from oracle import deformation_ref as R
+    from oracle import deformation_torch as T
+    from scene.deformation import deform_network
+    a = R.Args(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000)
+    torch.manual_seed(5)
+    net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
+    with torch.no_grad():
+        net.weight.mul_(100.0)
+    g = torch.Generator().manual_seed(6)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    base = dict(xyz=mk(P, 3), scales=mk(P, 3, sc=0.3) - 4, rot=mk(P, 4), opacity=mk(P, 1), sh=mk(P, 16, 3, sc=0.5),
+                emb=mk(P, 32, sc=0.1))
+    it, t = 20000, 0.43
+    # CPU restatement (float64) with autograd
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    b64 = {k: v.double().requires_grad_(True) for k, v in base.items()}
+    mg = []
+    fin, sub = T.forward(sd64, a, 1, 150, b64["xyz"], b64["scales"], b64["rot"], b64["opacity"], b64["sh"], b64["emb"],
+                         t, None, it, 30, 30, margin_out=mg)
+    # Gaussians sitting on a ReLU kink (|pre-activation| within fp32 rounding of 0) have a discontinuous gradient:
+    # they are taken out of the loss (both paths), so every compared gradient is well-conditioned.
+    keep = (mg[0] > 1e-6).float()
+    assert keep.mean() > 0.9
+    ws = [mk(*x.shape) * keep.reshape(-1, *([1] * (x.dim() - 1))) for x in list(fin) + list(sub)]
+    loss = sum((x * w.double()).sum() for x, w in zip(list(fin) + list(sub), ws))
+    loss.backward()
+    # HIP
+    net = net.cuda()
+    bg = {k: v.cuda().requires_grad_(True) for k, v in base.items()}
+    outs = net(bg["xyz"], bg["scales"], bg["rot"], bg["opacity"], t, None, _PC(bg["emb"]), None, bg["sh"], iter=it,
+               num_down_emb_c=30, num_down_emb_f=30)
+    hf, hs = outs[:5], outs[5][0]
+    lossg = sum((x * w.cuda().reshape(x.shape)).sum() for x, w in zip(list(hf) + list(hs), ws))
+    lossg.backward()
+    errs = {}
+    for n, x, y in zip(NAMES, hf, fin):
+        errs["out_" + n] = rel(x.detach().cpu().numpy(), y.detach().numpy())
+    for n, x, y in zip(NAMES, hs, sub):
+        errs["sub_" + n] = rel(x.detach().cpu().numpy(), y.detach().numpy())
+    for name, p in net.named_parameters():
+        ref = sd64[name].grad
+        if ref is None or float(ref.abs().max()) == 0:
+            continue
+        errs["g_" + name] = rel(p.grad.cpu().numpy(), ref.numpy())
+    for k in base:
+        errs["gin_" + k] = rel(bg[k].grad.cpu().numpy(), b64[k].grad.numpy())
+    print("P", P, "W", W, "max err", max(errs.values()), "worst", max(errs, key=errs.get))
+    for k, v in errs.items():
+        assert v <= TOL, (k, v)
