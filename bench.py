@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native E-D3DGS hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" = one pass of the hot path over one (camera, frame) item: gaussian_renderer.render() forward (fused
+deformation MLP -> activations -> preprocess -> binning -> tile forward) + backward (tile backward -> per-Gaussian
+backward -> activations -> deformation backward), i.e. one train.py iteration without data loading / optimizer
+(SURVEY.md 8d).  Workload = BASELINE.json configs[2] ("C3"): 200k Gaussians, 8 synthetic 1080p cameras x 50
+timesteps, deformation on (W=128, D=1, nersemble flags, iter=20000), depth+normal variant.  Items are sharded
+i = rank (mod N) (weak scaling: every rank runs K steps) with one 12-byte all-reduce of [loss, psnr, count] per step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+WORKLOADS = {
+    "C3": dict(P=200_000, W=1920, H=1080, cams=8, frames=50, deform=True,
+               name="C3: 200k Gaussians, 8 cams x 50 timesteps, 1080p, deform MLP W=128 D=1, depth+normal (FTT)"),
+    "C2": dict(P=100_000, W=1920, H=1080, cams=1, frames=1, deform=False,
+               name="C2: 100k Gaussians, 1 cam 1080p, static, depth+normal (FTT)"),
+    "tiny": dict(P=10_000, W=400, H=400, cams=2, frames=4, deform=True, name="tiny: 10k Gaussians 400x400 (plumbing)"),
+}
+
+
+def build(workload, device):
+    from ed3dgs_amd import synthetic as S
+    from ed3dgs_amd.model import SynthGaussianModel, default_hyper
+    wl = WORKLOADS[workload]
+    scene = S.make_scene(wl["P"], seed=0)
+    cams = S.make_cameras(wl["cams"], wl["W"], wl["H"], seed=1, device=device)
+    hyper = default_hyper() if wl["deform"] else default_hyper(no_coarse_deform=True, no_fine_deform=True)
+    model = SynthGaussianModel(scene, args=hyper, deform_seed=2, device=device)
+    grads = {k: v.to(device) for k, v in S.make_upstream_grads(wl["H"], wl["W"], seed=3).items()}
+    return wl, model, cams, grads
+
+
+def make_step(model, cams, grads, wl, device):
+    from ed3dgs_amd import dist as D
+    from ed3dgs_amd.model import PIPE
+    from gaussian_renderer import render
+    bg = torch.ones(3, device=device)
+    params = model.parameters()
+    F = wl["frames"]
+
+    def step(item, backward=True, coord=False):
+        ci, fi = D.item_of(item, wl["cams"], F)
+        cam = cams[ci].with_time(fi / F)
+        pkg = render(cam, model, PIPE, bg, kernel_size=0.0, require_coord=coord, require_depth=True, cam_no=None,
+                     iter=20000, num_down_emb_c=30, num_down_emb_f=30, disable_filter3D=True)
+        if not backward:
+            return pkg, None
+        # fixed upstream gradients stand in for the L1/SSIM + depth-normal losses
+        loss = ((pkg["render"] * grads["color"]).sum() + (pkg["expected_depth"] * grads["depth"]).sum() +
+                (pkg["median_depth"] * grads["mdepth"]).sum() + (pkg["normal"] * grads["normal"]).sum())
+        loss.backward()
+        mse = (pkg["render"].detach() - 0.5).square().mean()
+        stats = torch.stack([loss.detach(), -10.0 * torch.log10(mse), torch.ones((), device=device)])
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(stats)  # the path's one collective (RCCL over xGMI)
+        for p in params:
+            p.grad = None
+        pkg["viewspace_points"].grad = None
+        return pkg, stats
+
+    return step
+
+
+def r_eff_of_last(wl):
+    """R_eff = sum over tiles of the largest last-contributor index in the tile, from the image state."""
+    from diff_gaussian_rasterization import _C
+    L = _C.LAST
+    nc = _C.n_contrib_view(L["P"], L["H"], L["W"], L["R"], L["geom"], L["img"])[0]
+    H, W = L["H"], L["W"]
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = torch.zeros(gy * 16, gx * 16, dtype=nc.dtype, device=nc.device)
+    pad[:H, :W] = nc
+    return int(pad.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).sum()), int(nc.sum()), int(L["R"])
+
+
+def cpu_baseline(wl, seconds_budget=25.0):
+    """PyTorch-CPU autograd restatement (oracle/) of the same step on a bounded sample, all host cores."""
+    from ed3dgs_amd import synthetic as S
+    from ed3dgs_amd.model import default_hyper
+    from oracle import deformation_torch as DT
+    from oracle import torch_raster as TR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    scene = S.make_scene(wl["P"], seed=0)
+    cam = S.make_cameras(wl["cams"], wl["W"], wl["H"], seed=1)[0]
+    hyper = default_hyper()
+    leaf = lambda t: t.clone().requires_grad_(True)
+    xyz, ls, rot, op = leaf(scene.xyz), leaf(scene.log_scale), leaf(scene.rot), leaf(scene.opacity)
+    sh = leaf(torch.cat((scene.f_dc, scene.f_rest), 1))
+    emb = leaf(scene.embedding)
+    t0 = time.perf_counter()
+    if wl["deform"]:
+        from scene.deformation import deform_network
+        torch.manual_seed(2)
+        net = deform_network(W=hyper.net_width, D=hyper.defor_depth, min_embeddings=30, max_embeddings=150, args=hyper)
+        with torch.no_grad():
+            net.weight.mul_(100.0)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        (xyz_f, ls_f, rot_f, op_f, sh_f), _ = DT.forward(sd, hyper, 1, 150, xyz, ls, rot, op, sh, emb, 0.0, None, 20000, 30, 30)
+    else:
+        xyz_f, ls_f, rot_f, op_f, sh_f = xyz, ls, rot, op, sh
+    scales = torch.exp(ls_f); rots = torch.nn.functional.normalize(rot_f); opac = torch.sigmoid(op_f)
+    T = ((wl["W"] + 15) // 16) * ((wl["H"] + 15) // 16)
+    stride = max(1, T // 400)
+    subset = list(range(stride // 2, T, stride))
+    out = TR.rasterize(torch.ones(3), xyz_f, opac, scales, rots, sh_f, cam.world_view_transform, cam.full_proj_transform,
+                       cam.camera_center, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0.0, wl["H"], wl["W"], 3,
+                       False, True, tile_subset=subset)
+    g = S.make_upstream_grads(wl["H"], wl["W"], seed=3)
+    loss = ((out["color"] * g["color"]).sum() + (out["depth"] * g["depth"]).sum() + (out["mdepth"] * g["mdepth"]).sum() +
+            (out["normal"] * g["normal"]).sum())
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    # per-Gaussian work (deformation, preprocess, binning and their backward) ran in full; only the tile compositing
+    # was sub-sampled, and is scaled by the tile ratio.  The split between the two is not timed separately, so the
+    # whole measured time is scaled -- a LOWER bound on the CPU step time would be t_meas, an upper bound t_meas*ratio;
+    # the figure reported is the upper bound's reciprocal (conservative for the CPU).
+    t_meas = t2 - t0
+    ratio = T / len(subset)
+    return dict(value=1.0 / (t_meas * ratio), unit="iters/s", cores=cores, kind="port",
+                sample=(f"1 item of the workload; deformation+preprocess+binning in full, tile compositing fwd+bwd on "
+                        f"{len(subset)} of {T} tiles (every {stride}th), measured {t_meas:.1f} s "
+                        f"(fwd {t1 - t0:.1f} s, bwd {t2 - t1:.1f} s), scaled x{ratio:.1f}; PyTorch-CPU autograd "
+                        f"restatement (oracle/torch_raster.py + oracle/deformation_torch.py), fp32"),
+                measured_seconds=round(t_meas, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from ed3dgs_amd import dist as D
+    from ed3dgs_amd import _lib
+    rank, world, local = D.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    L = _lib.lib()
+    from diff_gaussian_rasterization import _C
+    wl, model, cams, grads = build(a.workload, device)
+    step = make_step(model, cams, grads, wl, device)
+    n_items = wl["cams"] * wl["frames"]
+    my_items = D.shard_items(max(n_items, world), rank, world)
+    item_at = lambda k: my_items[k % len(my_items)] % n_items
+
+    # ---- untimed: warm-up + algorithmic-byte bookkeeping of the items the timed region will visit ----
+    _C.KEEP_LAST = True
+    for k in range(a.warmup):
+        step(item_at(k))
+    reff, npairs_ub, rsum = [], [], []
+    with torch.no_grad():
+        for k in range(a.steps):
+            step(item_at(k), backward=False)
+            r, n, R = r_eff_of_last(wl)
+            reff.append(r); npairs_ub.append(n); rsum.append(R)
+    _C.KEEP_LAST = False
+    _C.LAST.clear()
+
+    # ---- timed: exactly K steps ----
+    torch.cuda.synchronize(); D.barrier()
+    L.ed3dgs_profile_begin(ctypes.c_int(a.steps + 4))
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(item_at(k))
+    torch.cuda.synchronize(); D.barrier()
+    dt = time.perf_counter() - t0
+    f_ms, f_n, b_ms, b_n = ctypes.c_double(), ctypes.c_int(), ctypes.c_double(), ctypes.c_int()
+    L.ed3dgs_profile_end(ctypes.byref(f_ms), ctypes.byref(f_n), ctypes.byref(b_ms), ctypes.byref(b_n))
+    dt = D.max_over_ranks(dt, device)
+
+    # ---- forward-only render fps (render.py's TTT variant), untimed w.r.t. the headline ----
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        t1 = time.perf_counter()
+        for k in range(a.steps):
+            step(item_at(k), backward=False, coord=True)
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t1
+    dt_r = D.max_over_ranks(dt_r, device)
+
+    if rank != 0:
+        return
+    HW, T = wl["H"] * wl["W"], ((wl["W"] + 15) // 16) * ((wl["H"] + 15) // 16)
+    mean = lambda v: sum(v) / max(len(v), 1)
+    bytes_k7 = 128.0 * mean(reff) + 68.0 * HW + 8.0 * T   # FTT: (g_b + 4a) R_eff + r HW + 8T  
+    bytes_k6 = 68.0 * mean(reff) + 56.0 * HW + 8.0 * T
+    k7_ms = b_ms.value / max(b_n.value, 1)
+    k6_ms = f_ms.value / max(f_n.value, 1)
+    ach = bytes_k7 / (k7_ms * 1e-3) / 1e9 if k7_ms > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            if pj.get("workload") == a.workload:
+                traffic = pj.get("render_backward_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "train iters/sec @200k Gaussians 1080p (fwd+bwd of render() incl. deformation MLP)",
+        "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "gaussians": wl["P"], "resolution": [wl["W"], wl["H"]],
+                   "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step",
+                   "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
+        "render_fps": world * a.steps / dt_r,
+        "render_fps_note": "forward only, all outputs (coord+depth+normal), torch.no_grad, incl. deformation",
+        "roofline": {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": b_n.value,
+                     "forward_kernel_avg_launch_ms": k6_ms,
+                     "forward_kernel_GBps": bytes_k6 / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else 0.0,
+                     "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
+                     "note": "K7 is VALU/LDS-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM "
+                             "fraction is reported as defined there, next to the pair rate"},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(wl)
+        except Exception as ex:  # the baseline is a reported extra; a failure must not lose the GPU measurement
+            res["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -66,6 +67,15 @@ static uint32_t higher_msb(uint32_t n)
 }
 
 static inline size_t tiles_of(int W, int H) { return (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+
+// ---- optional kernel timing (bench.py): event pairs around the two tile kernels ----
+struct Profiler {
+    bool on = false;
+    int cap = 0, nf = 0, nb = 0;
+    std::vector<hipEvent_t> f0, f1, b0, b1;
+};
+static Profiler g_prof;
+static void prof_mark(std::vector<hipEvent_t> &ev, int idx, hipStream_t s) { (void)hipEventRecord(ev[idx], s); }
 
 struct StageCheck {
     bool debug; hipStream_t s;
@@ -177,9 +187,12 @@ int ed3dgs_rasterize_forward(
     launch_identify_tile_ranges(R, bin.keys, img.ranges, s);
     if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
 
+    const bool pf = g_prof.on && g_prof.nf < g_prof.cap;
+    if (pf) prof_mark(g_prof.f0, g_prof.nf, s);
     launch_render_forward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
                           background, require_coord != 0, require_depth != 0, out_color, out_coord, out_mcoord,
                           out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img, s);
+    if (pf) prof_mark(g_prof.f1, g_prof.nf++, s);
     if (!ok("render")) return ED3DGS_ERR_HIP;
     return R;
 }
@@ -226,10 +239,13 @@ int ed3dgs_rasterize_backward(
     if (!check_hip(hipMemsetAsync(grec, 0, zero_bytes, s), "memset gradient records")) return ED3DGS_ERR_HIP;
 
     if (R > 0) {
+        const bool pb = g_prof.on && g_prof.nb < g_prof.cap;
+        if (pb) prof_mark(g_prof.b0, g_prof.nb, s);
         launch_render_backward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
                                background, require_coord != 0, require_depth != 0, alphas, normalmap, img, dL_dpix,
                                dL_dpix_coord, dL_dpix_mcoord, dL_dpix_depth, dL_dpix_mdepth, dL_dalphas,
                                dL_dpix_normal, grec, grec_coord, s);
+        if (pb) prof_mark(g_prof.b1, g_prof.nb++, s);
         if (!ok("render backward")) return ED3DGS_ERR_HIP;
     }
     launch_preprocess_backward(P, D, M, means3D, radii, shs, scales, rotations, scale_modifier, cov3D_precomp,
@@ -237,6 +253,35 @@ int ed3dgs_rasterize_backward(
                                grec, grec_coord, colors_precomp != nullptr, q1_reference != 0, width, height,
                                dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s);
     if (!ok("preprocess backward")) return ED3DGS_ERR_HIP;
+    return 0;
+}
+
+int ed3dgs_profile_begin(int max_samples)
+{
+    if (g_prof.on || max_samples <= 0) { set_error("ed3dgs_profile_begin: already active or bad size"); return ED3DGS_ERR_INVALID; }
+    g_prof = Profiler();
+    g_prof.cap = max_samples;
+    for (auto *v : {&g_prof.f0, &g_prof.f1, &g_prof.b0, &g_prof.b1}) {
+        v->resize(max_samples);
+        for (auto &e : *v) if (!check_hip(hipEventCreate(&e), "hipEventCreate")) return ED3DGS_ERR_HIP;
+    }
+    g_prof.on = true;
+    return 0;
+}
+
+int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches)
+{
+    if (!g_prof.on) { set_error("ed3dgs_profile_end: not active"); return ED3DGS_ERR_INVALID; }
+    g_prof.on = false;
+    double tf = 0, tb = 0;
+    for (int i = 0; i < g_prof.nf; i++) { float ms = 0; (void)hipEventSynchronize(g_prof.f1[i]); (void)hipEventElapsedTime(&ms, g_prof.f0[i], g_prof.f1[i]); tf += ms; }
+    for (int i = 0; i < g_prof.nb; i++) { float ms = 0; (void)hipEventSynchronize(g_prof.b1[i]); (void)hipEventElapsedTime(&ms, g_prof.b0[i], g_prof.b1[i]); tb += ms; }
+    if (fwd_ms_total) *fwd_ms_total = tf;
+    if (fwd_launches) *fwd_launches = g_prof.nf;
+    if (bwd_ms_total) *bwd_ms_total = tb;
+    if (bwd_launches) *bwd_launches = g_prof.nb;
+    for (auto *v : {&g_prof.f0, &g_prof.f1, &g_prof.b0, &g_prof.b1}) for (auto &e : *v) (void)hipEventDestroy(e);
+    g_prof = Profiler();
     return 0;
 }
 

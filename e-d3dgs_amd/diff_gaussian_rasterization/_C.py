@@ -13,6 +13,9 @@ from ed3dgs_amd import _lib
 NUM_CHANNELS = 3  # CR/config.h:15
 # SURVEY quirk Q1 (CR/rasterizer_impl.cu:576): True = behave like the reference binary.
 Q1_REFERENCE = True
+# bench.py / tests: when KEEP_LAST is set, the most recent forward's (num_rendered, H, W, state buffers) stay reachable
+KEEP_LAST = False
+LAST = {}
 
 
 def _ptr(t):
@@ -97,6 +100,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scal
             _ptr(out_tongue), _ptr(out_normal), _ptr(radii), C.c_int(rc), C.c_int(rd), C.c_int(bool(debug)), _stream())
         if rendered < 0:
             raise RuntimeError(_lib.last_error())
+    if KEEP_LAST:
+        LAST.update(P=P, H=H, W=W, R=rendered, geom=geom.t, binning=binning.t, img=img.t)
     return (rendered, out_color, out_coord, out_mcoord, out_alpha, out_tongue, out_normal, out_depth, out_mdepth,
             radii, geom.t, binning.t, img.t)
 
@@ -163,6 +168,18 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 def integrate_gaussians_to_points(*args, **kwargs):
     # DGR/rasterize_points.cu:273-392 (mesh-extraction probe).  SURVEY section 8(f) rank 1: next, not built yet.
     raise NotImplementedError("integrate_gaussians_to_points is outside this round's hot-path scope (SURVEY 8f.1)")
+
+
+def n_contrib_view(P, H, W, R, geomBuffer, imageBuffer):
+    """(2,H,W) int32 GPU tensor aliasing the image state's n_contrib planes (last / median contributor)."""
+    L = _lib.lib()
+    sv = _lib.StateView()
+    rc = L.ed3dgs_state_view_get(C.c_int(P), C.c_int(W), C.c_int(H), C.c_int(R), _ptr(geomBuffer), None,
+                                 _ptr(imageBuffer), C.byref(sv))
+    if rc < 0:
+        raise RuntimeError(_lib.last_error())
+    off = sv.n_contrib - imageBuffer.data_ptr()
+    return imageBuffer[off:off + 2 * H * W * 4].view(torch.int32).reshape(2, H, W)
 
 
 def state_view(P, H, W, R, geomBuffer, binningBuffer, imageBuffer):

@@ -1,0 +1,143 @@
+"""gaussian_renderer -- MI355X-native drop-in for the reference's render glue (gaussian_renderer/__init__.py).
+
+`render`, `render_tongue`, `render_without_tongue` keep the reference's signatures (:8, :145, :289) and result-dict
+keys (:128-142), so train.py / render.py call them unchanged.  What differs is how it runs:
+  * scalars of the raster settings are plain Python numbers (the reference wraps six of them in 0-d CUDA tensors
+    that pybind turns back into host scalars -> six device syncs per call, :29-37);
+  * the camera time is passed to the deformation network as a float (no (P,1) tensor, :45);
+  * deformation = one fused HIP launch per direction, activations fused, rasterizer = HIP tile kernels.
+`render_old` / `integrate` (DGR-old and mesh probing) are outside this round's hot-path scope.
+"""
+import math
+
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord, require_depth):
+    dev = pc.get_xyz.device
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
+        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        kernel_size=float(kernel_size),
+        bg=bg_color.to(dev),
+        scale_modifier=float(scaling_modifier),
+        viewmatrix=viewpoint_camera.world_view_transform.to(dev),
+        projmatrix=viewpoint_camera.full_proj_transform.to(dev),
+        sh_degree=int(pc.active_sh_degree),
+        campos=viewpoint_camera.camera_center.to(dev),
+        prefiltered=False,
+        require_depth=bool(require_depth),
+        require_coord=bool(require_coord),
+        debug=bool(pipe.debug),
+    )
+
+
+def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord, require_depth,
+                 override_color, cam_no, iter, num_down_emb_c, num_down_emb_f, disable_filter3D, select):
+    """select: None = all Gaussians; +1 = rows with round(tongue_class) != 0 (render_tongue :155,246-253);
+    -1 = the complement (render_without_tongue :299,390-397).  Deformation always runs on all P."""
+    means3D = pc.get_xyz
+    # zero tensor whose .grad receives the screen-space mean gradients (train.py:346-348 reads it)
+    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    raster_settings = _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord,
+                                require_depth)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    opacity = pc._opacity
+    shs = pc.get_features
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc._scaling
+        rotations = pc._rotation
+
+    (means3D_final, scales_final, rotations_final, opacity_final, shs_final, extras) = pc._deformation(
+        means3D, scales, rotations, opacity, float(viewpoint_camera.time), cam_no, pc, None, shs, iter=iter,
+        num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f)
+
+    rotations_final = pc.rotation_activation(rotations_final)
+    if disable_filter3D:
+        scales_final = pc.scaling_activation(scales_final)
+        opacity = pc.opacity_activation(opacity_final)
+    else:
+        scales_final, opacity = pc.apply_scaling_n_opacity_with_3D_filter(opacity=opacity_final, scales=scales_final)
+
+    colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            from utils.sh_utils import eval_sh  # only when the caller asks for the Python SH path
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.to(means3D.device).repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+    else:
+        colors_precomp = override_color
+
+    tongue_class = pc.tongue_class
+    m3, m2, sh_r, op_r, sc_r, ro_r, cp_r, cov_r, tg_r = (means3D_final, screenspace_points, shs_final, opacity,
+                                                       scales_final, rotations_final, colors_precomp, cov3D_precomp,
+                                                       tongue_class)
+    mask = None
+    if select is not None:
+        is_tongue = torch.round(tongue_class).bool().reshape(-1)  # filter_mask of the reference (:155, :299)
+        mask = is_tongue if select > 0 else ~is_tongue
+        pick = lambda t: None if t is None else t[mask]
+        m3, m2, sh_r, op_r, sc_r, ro_r, cp_r, cov_r, tg_r = [pick(t) for t in (m3, m2, sh_r, op_r, sc_r, ro_r, cp_r,
+                                                                              cov_r, tg_r)]
+    if colors_precomp is not None:
+        sh_r = None
+
+    outputs = rasterizer(means3D=m3, means2D=m2, shs=sh_r, colors_precomp=cp_r, opacities=op_r, tongue_class=tg_r,
+                         scales=sc_r, rotations=ro_r, cov3D_precomp=cov_r)
+    assert len(outputs) == 9, "only (depth-)diff-gaussian-rasterization from RaDe-GS supported!"
+    (rendered_image, radii, expected_coord, median_coord, expected_depth, median_depth, rendered_alpha,
+     rendered_tongue, rendered_normal) = outputs
+    # note: for the masked variants `radii` / `visibility_filter` have the subset's length, as in the reference
+    return {"render": rendered_image,
+            "mask": rendered_alpha,
+            "expected_coord": expected_coord,
+            "median_coord": median_coord,
+            "expected_depth": expected_depth,
+            "median_depth": median_depth,
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii,
+            "normal": rendered_normal,
+            "sh_coefs_final": shs_final,
+            "extras": extras,
+            "deformed_gaussian_positions": means3D_final,
+            "tongue_mask": rendered_tongue}
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, kernel_size, scaling_modifier=1.0,
+           require_coord: bool = True, require_depth: bool = True, override_color=None, cam_no=None, iter=None,
+           train_coarse=False, num_down_emb_c=5, num_down_emb_f=5, disable_filter3D=True):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+    return _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord,
+                        require_depth, override_color, cam_no, iter, num_down_emb_c, num_down_emb_f, disable_filter3D,
+                        None)
+
+
+def render_tongue(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, kernel_size, scaling_modifier=1.0,
+                  require_coord: bool = True, require_depth: bool = True, override_color=None, cam_no=None, iter=None,
+                  train_coarse=False, num_down_emb_c=5, num_down_emb_f=5, disable_filter3D=True):
+    return _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord,
+                        require_depth, override_color, cam_no, iter, num_down_emb_c, num_down_emb_f, disable_filter3D,
+                        +1)
+
+
+def render_without_tongue(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, kernel_size, scaling_modifier=1.0,
+                          require_coord: bool = True, require_depth: bool = True, override_color=None, cam_no=None,
+                          iter=None, train_coarse=False, num_down_emb_c=5, num_down_emb_f=5, disable_filter3D=True):
+    return _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord,
+                        require_depth, override_color, cam_no, iter, num_down_emb_c, num_down_emb_f, disable_filter3D,
+                        -1)

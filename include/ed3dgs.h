@@ -126,6 +126,12 @@ typedef struct ed3dgs_state_view {
 int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geometry_buffer,
                           const char *binning_buffer, const char *image_buffer, ed3dgs_state_view *out);
 
+/* Measurement aid (bench.py): while enabled, the tile forward (K6) and tile backward (K7) launches are bracketed by
+ * hipEvents on the stream they are launched on; ed3dgs_profile_end synchronises those events and returns the summed
+ * kernel durations in milliseconds and the launch counts.  Not part of the data path. */
+int ed3dgs_profile_begin(int max_samples);
+int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches);
+
 /* ---------------- deformation MLP (scene/deformation.py) ---------------- */
 /*
  * deform_network.forward (scene/deformation.py:108-141) as fused launches: the per-frame temporal row
