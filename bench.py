@@ -91,13 +91,26 @@ def r_eff_of_last(wl):
     return int(pad.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).sum()), int(nc.sum()), int(L["R"])
 
 
-def cpu_baseline(wl, seconds_budget=25.0):
-    """PyTorch-CPU autograd restatement (oracle/) of the same step on a bounded sample, all host cores."""
+def host_cores():
+    """Cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota (a GPU box hands each
+    job a share of a much larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(wl):
+    """PyTorch-CPU autograd restatement (oracle/) of the same step on a bounded sample, all usable host cores."""
     from ed3dgs_amd import synthetic as S
     from ed3dgs_amd.model import default_hyper
     from oracle import deformation_torch as DT
     from oracle import torch_raster as TR
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     scene = S.make_scene(wl["P"], seed=0)
     cam = S.make_cameras(wl["cams"], wl["W"], wl["H"], seed=1)[0]
@@ -121,27 +134,33 @@ def cpu_baseline(wl, seconds_budget=25.0):
     T = ((wl["W"] + 15) // 16) * ((wl["H"] + 15) // 16)
     stride = max(1, T // 400)
     subset = list(range(stride // 2, T, stride))
-    out = TR.rasterize(torch.ones(3), xyz_f, opac, scales, rots, sh_f, cam.world_view_transform, cam.full_proj_transform,
-                       cam.camera_center, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0.0, wl["H"], wl["W"], 3,
-                       False, True, tile_subset=subset)
+    pp = TR.preprocess(xyz_f, scales, rots, opac, sh_f, cam.world_view_transform, cam.full_proj_transform,
+                       cam.camera_center, wl["W"], wl["H"], math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0.0, 1.0, 3)
+    ids, starts = TR.bin_tiles(pp)
+    t_pg = time.perf_counter() - t0            # per-Gaussian part, run in full
+    out = TR.render(pp, ids, starts, torch.ones(3), wl["W"], wl["H"], False, True, tile_subset=subset)
     g = S.make_upstream_grads(wl["H"], wl["W"], seed=3)
     loss = ((out["color"] * g["color"]).sum() + (out["depth"] * g["depth"]).sum() + (out["mdepth"] * g["mdepth"]).sum() +
             (out["normal"] * g["normal"]).sum())
+    t_tiles = time.perf_counter() - t0 - t_pg  # tile compositing on the sub-sample
     t1 = time.perf_counter()
     loss.backward()
-    t2 = time.perf_counter()
-    # per-Gaussian work (deformation, preprocess, binning and their backward) ran in full; only the tile compositing
-    # was sub-sampled, and is scaled by the tile ratio.  The split between the two is not timed separately, so the
-    # whole measured time is scaled -- a LOWER bound on the CPU step time would be t_meas, an upper bound t_meas*ratio;
-    # the figure reported is the upper bound's reciprocal (conservative for the CPU).
-    t_meas = t2 - t0
+    t_bwd = time.perf_counter() - t1
+    # only the tile compositing is sub-sampled (every `stride`-th tile) and scaled by the tile ratio; the backward is
+    # not separable, so it is scaled by the same factor the forward's total grows by.
     ratio = T / len(subset)
-    return dict(value=1.0 / (t_meas * ratio), unit="iters/s", cores=cores, kind="port",
-                sample=(f"1 item of the workload; deformation+preprocess+binning in full, tile compositing fwd+bwd on "
-                        f"{len(subset)} of {T} tiles (every {stride}th), measured {t_meas:.1f} s "
-                        f"(fwd {t1 - t0:.1f} s, bwd {t2 - t1:.1f} s), scaled x{ratio:.1f}; PyTorch-CPU autograd "
-                        f"restatement (oracle/torch_raster.py + oracle/deformation_torch.py), fp32"),
-                measured_seconds=round(t_meas, 2))
+    fwd_est = t_pg + t_tiles * ratio
+    est = fwd_est + t_bwd * fwd_est / (t_pg + t_tiles)
+    return dict(value=1.0 / est, unit="iters/s", cores=cores, kind="port",
+                sample=(f"1 item of the workload; deformation+preprocess+binning in full ({t_pg:.1f} s), tile compositing "
+                        f"on {len(subset)} of {T} tiles (every {stride}th, {t_tiles:.1f} s, scaled x{ratio:.1f}), autograd "
+                        f"backward {t_bwd:.1f} s scaled by the forward's growth; estimated {est:.0f} s per step; "
+                        f"PyTorch-CPU autograd restatement (oracle/torch_raster.py + oracle/deformation_torch.py), fp32"),
+                measured_seconds=round(t_pg + t_tiles + t_bwd, 2))
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
 
 
 def main():
@@ -162,7 +181,9 @@ def main():
     device = f"cuda:{local}"
     L = _lib.lib()
     from diff_gaussian_rasterization import _C
+    log("building workload", a.workload)
     wl, model, cams, grads = build(a.workload, device)
+    log("built; warm-up")
     step = make_step(model, cams, grads, wl, device)
     n_items = wl["cams"] * wl["frames"]
     my_items = D.shard_items(max(n_items, world), rank, world)
@@ -172,6 +193,8 @@ def main():
     _C.KEEP_LAST = True
     for k in range(a.warmup):
         step(item_at(k))
+    torch.cuda.synchronize()
+    log("warm-up done; bookkeeping pass")
     reff, npairs_ub, rsum = [], [], []
     with torch.no_grad():
         for k in range(a.steps):
@@ -183,6 +206,7 @@ def main():
 
     # ---- timed: exactly K steps ----
     torch.cuda.synchronize(); D.barrier()
+    log("timed region")
     L.ed3dgs_profile_begin(ctypes.c_int(a.steps + 4))
     t0 = time.perf_counter()
     for k in range(a.steps):
@@ -193,6 +217,7 @@ def main():
     L.ed3dgs_profile_end(ctypes.byref(f_ms), ctypes.byref(f_n), ctypes.byref(b_ms), ctypes.byref(b_n))
     dt = D.max_over_ranks(dt, device)
 
+    log("timed region done: %.3f ms/step" % (dt / a.steps * 1e3))
     # ---- forward-only render fps (render.py's TTT variant), untimed w.r.t. the headline ----
     torch.cuda.synchronize()
     with torch.no_grad():
@@ -241,6 +266,7 @@ def main():
                              "fraction is reported as defined there, next to the pair rate"},
     }
     if world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline (bounded sample, ~15-30 s)")
         try:
             res["cpu_baseline"] = cpu_baseline(wl)
         except Exception as ex:  # the baseline is a reported extra; a failure must not lose the GPU measurement

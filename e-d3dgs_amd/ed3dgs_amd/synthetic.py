@@ -16,7 +16,7 @@ def make_scene(P, seed=0, device="cpu", sh_degree=3, embedding_dim=32):
     """Raw (pre-activation) Gaussian parameters, as GaussianModel stores them (scene/gaussian_model.py:48-71)."""
     g = torch.Generator().manual_seed(seed)
     xyz = torch.rand(P, 3, generator=g) * 2 - 1
-    mean_ls = math.log(0.6 * P ** (-1.0 / 3.0))
+    mean_ls = math.log(0.6 * max(P, 1) ** (-1.0 / 3.0))
     log_scale = torch.randn(P, 3, generator=g) * 0.4 + mean_ls
     rot = torch.randn(P, 4, generator=g)
     opacity = torch.randn(P, 1, generator=g) * 1.5

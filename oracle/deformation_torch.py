@@ -11,9 +11,32 @@ from . import deformation_ref as R
 
 
 def temporal_row(weight, t, n):
-    rows, coefs = R.temporal_embed_lerp_coefs(weight.shape[0], t, n)
+    """t: 0-d tensor (may require grad).  The row indices are piecewise constant in t; the lerp weight is linear with
+    slope +-(n-1) (reflection flips the sign), which is how grid_sample back-propagates into the time offset."""
+    tv = float(t)
+    rows, coefs = R.temporal_embed_lerp_coefs(weight.shape[0], tv, n)
     c = torch.tensor(coefs, dtype=weight.dtype)
-    return (weight[rows] * c[:, None]).sum(0)
+    h = (weight[rows] * c[:, None]).sum(0)
+    if n > 1 and torch.is_tensor(t) and t.requires_grad:
+        y = tv * (n - 1)
+        span = n - 1
+        sgn = -1.0 if y < 0 else 1.0
+        if int(abs(y) // span) % 2 == 1:
+            sgn = -sgn
+        wa, wb = c[0] + c[1], c[2] + c[3]
+        rowA = (weight[rows[0]] * c[0] + weight[rows[1]] * c[1]) / wa if float(wa) > 0 else weight[rows[0]]
+        # resized rows at y0 / y1 (independent of the lerp weight)
+        E = weight.shape[0]
+        def resized(yy):
+            src = yy * (E - 1) / (n - 1)
+            i0 = min(int(src // 1), E - 1); i1 = min(i0 + 1, E - 1)
+            l1 = src - i0
+            return weight[i0] * (1 - l1) + weight[i1] * l1
+        yv = abs(y) % span if int(abs(y) // span) % 2 == 0 else span - (abs(y) % span)
+        y0 = int(yv // 1); y1 = min(y0 + 1, n - 1)
+        dh = (resized(y1) - resized(y0)).detach() * (sgn * (n - 1))
+        h = h + dh * (t - t.detach())
+    return h
 
 
 def forward(sd, args, D, max_embeddings, xyz, scales, rot, opacity, sh, emb, time, cam_no, it, num_down_emb_c,
@@ -27,7 +50,7 @@ def forward(sd, args, D, max_embeddings, xyz, scales, rot, opacity, sh, emb, tim
         offset = nz.mean() if nz.numel() else torch.zeros((), dtype=off.dtype)
     else:
         offset = off[cam_no, 0]
-    t = float(time) + float(offset)  # offsets receive no gradient through the piecewise-linear table lookup here
+    t = offset + float(time) if torch.is_tensor(offset) else torch.tensor(float(time) + float(offset))
     coef, coef_c, coef_o, coef_s = R.anneal_coefs(args, it)
     n_c, n_f = R.row_counts(args, it, max_embeddings, num_down_emb_c, num_down_emb_f)
     cur = [xyz, scales, rot, opacity.reshape(-1, 1), sh]

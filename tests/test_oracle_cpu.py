@@ -1,0 +1,392 @@
+"""CPU suite (-m "not gpu"): pins the oracle, checks the host logic and the C-ABI library's exports.
+
+The reference holds no golden vectors for the rasterizer ("parity unpinned by the reference"), so the
+C restatement is pinned by hand-derived known answers, structural invariants, and an independent PyTorch-autograd
+restatement (values and gradients).  The deformation restatements are pinned by fixtures generated from the
+reference's own scene/deformation.py (tests/golden/, tools/gen_golden.py)."""
+import glob
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from ed3dgs_amd import synthetic as S
+from oracle import deformation_ref as DR
+from oracle import deformation_torch as DT
+from oracle import raster_oracle as O
+from oracle import torch_raster as TR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "deform_*.npz")))
+
+
+# ---------------------------------------------------------------- eigen-solver
+def test_eig_solver_reconstructs_and_matches_numpy():
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        A = rng.randn(3, 3).astype(np.float32) * rng.choice([0.05, 1.0, 3.0])
+        cov = (A @ A.T).astype(np.float32)
+        cov6 = np.array([cov[0, 0], cov[0, 1], cov[0, 2], cov[1, 1], cov[1, 2], cov[2, 2]], np.float32)
+        n, val, vec = O.eig_sym3(cov6)
+        assert n == 3
+        rec = sum(val[k] * np.outer(vec[k], vec[k]) for k in range(3))
+        scale = np.abs(cov).max()
+        assert np.abs(rec - cov).max() <= 2e-5 * scale + 3e-7  # absolute 1e-7 thresholds of the solver (CR/auxiliary.h:237)
+        ref = np.linalg.eigvalsh(cov.astype(np.float64))
+        assert np.abs(np.sort(val) - ref).max() <= 2e-5 * scale + 3e-7
+
+
+def test_eig_solver_diagonal_input_is_exact():
+    n, val, vec = O.eig_sym3(np.array([4.0, 0, 0, 9.0, 0, 1.0], np.float32))
+    assert n == 3 and sorted(val.tolist()) == [1.0, 4.0, 9.0]
+    assert np.allclose(np.abs(vec), np.eye(3)[[int(np.argmax(np.abs(vec[k]))) for k in range(3)]])
+
+
+# ---------------------------------------------------------------- known answers
+def _identity_camera(W, H, fx):
+    """Camera at the origin looking down +z: view = I, proj = perspective (znear .01 / zfar 100)."""
+    FoVx, FoVy = 2 * math.atan(W / (2 * fx)), 2 * math.atan(H / (2 * fx))
+    proj = S._projection(0.01, 100.0, FoVx, FoVy).transpose(0, 1).contiguous()
+    view = torch.eye(4)
+    return dict(viewmatrix=view, projmatrix=view @ proj, campos=torch.zeros(3), tanfovx=math.tan(FoVx / 2),
+                tanfovy=math.tan(FoVy / 2))
+
+
+def _single(W=64, H=48, fx=60.0, pos=(0.0, 0.0, 5.0), scale=0.2, opacity=0.7, rgb=(0.2, 0.6, 0.9), ks=0.0, bg=(1, 1, 1)):
+    cam = _identity_camera(W, H, fx)
+    sh = torch.zeros(1, 16, 3)
+    sh[0, 0] = (torch.tensor(rgb) - 0.5) / 0.28209479177387814  # so that SH_C0 * sh + 0.5 = rgb
+    return dict(P=1, W=W, H=H, bg=torch.tensor(bg, dtype=torch.float32), means3D=torch.tensor([pos]),
+                opacities=torch.tensor([[opacity]]), tongue_class=torch.ones(1, 1), scales=torch.full((1, 3), scale),
+                rotations=torch.tensor([[1.0, 0, 0, 0]]), shs=sh, kernel_size=ks, scale_modifier=1.0, sh_degree=3, **cam)
+
+
+def test_known_answer_single_isotropic_gaussian():
+    """One isotropic Gaussian on the optical axis: hand-derived mean pixel, conic, alpha, colour, depth, normal."""
+    W, H, fx, z, s, o = 64, 48, 60.0, 5.0, 0.2, 0.7
+    inp = _single(W, H, fx, (0, 0, z), s, o)
+    fw = util.oracle_forward(inp, "TTT")
+    # ndc 0 -> pixel ((0+1)*S-1)/2
+    assert np.allclose(fw["means2D"][0], [(W - 1) / 2, (H - 1) / 2], atol=1e-5)
+    sig2 = (fx * s / z) ** 2  # cov2D = J Sigma J^T = (fx/z)^2 s^2 I on the axis
+    assert np.allclose(fw["conic_opacity"][0], [1 / sig2, 0, 1 / sig2, o], rtol=2e-5)
+    assert fw["radii"][0] == math.ceil(3 * math.sqrt(sig2)) and fw["depths"][0] == z
+    assert np.allclose(fw["ts"][0], z) and np.allclose(fw["normals"][0], [0, 0, -1], atol=1e-5)
+    # pixel (31, 23): d = (0.5, 0.5) from the mean
+    px, py = 31, 23
+    d2 = 0.5 ** 2 + 0.5 ** 2
+    alpha = o * math.exp(-0.5 * d2 / sig2)
+    rgb = np.array([0.2, 0.6, 0.9])
+    assert np.allclose(fw["alpha"][0, py, px], alpha, rtol=1e-5)
+    assert np.allclose(fw["color"][:, py, px], alpha * rgb + (1 - alpha) * 1.0, rtol=1e-5)
+    assert np.allclose(fw["tongue"][0, py, px], alpha, rtol=1e-5)
+    assert np.allclose(fw["normal"][:, py, px], [0, 0, -1], atol=1e-5)
+    # a sphere-like Gaussian seen head-on: the ray-space plane is flat to first order, depth = ray length / ln
+    ln = math.sqrt(((px - W / 2) / fx) ** 2 + ((py - H / 2) / fx) ** 2 + 1)
+    t = fw["ts"][0] + fw["ray_planes"][0, 0] * ((W - 1) / 2 - px) + fw["ray_planes"][0, 1] * ((H - 1) / 2 - py)
+    assert np.allclose(fw["depth"][0, py, px], t / ln, rtol=1e-5) and np.allclose(fw["mdepth"][0, py, px], t / ln, rtol=1e-5)
+    assert abs(fw["depth"][0, py, px] - z) < 2e-2
+    assert np.allclose(fw["coord"][2, py, px], z, atol=2e-2)
+    assert fw["n_contrib"][0, py, px] == 1 and fw["n_contrib"][1, py, px] == 1
+    # far corner: untouched -> background, zero geometry, default n_contrib
+    assert np.allclose(fw["color"][:, 0, 0], 1.0) and fw["alpha"][0, 0, 0] == 0 and fw["depth"][0, 0, 0] == 0
+    assert fw["n_contrib"][0, 0, 0] == 0 and fw["n_contrib"][1, 0, 0] == 0xFFFFFFFF and fw["normal_length"][0, 0, 0] == 1
+
+
+def test_known_answer_alpha_clamp_threshold_and_mip_coef():
+    inp = _single(opacity=1.0, scale=0.5)
+    fw = util.oracle_forward(inp, "FFF")
+    assert abs(fw["alpha"].max() - 0.99) < 1e-6                          # min(0.99, .) (Q5)
+    a = fw["alpha"][fw["alpha"] > 0]
+    assert a.min() >= 1.0 / 255.0 - 1e-7                                 # skip below 1/255
+    # kernel_size > 0: opacity scaled by sqrt(det0/det1) (CR/forward.cu:119-124)
+    W, H, fx, z, s, ks = 64, 48, 60.0, 5.0, 0.02, 0.3
+    fw2 = util.oracle_forward(_single(W, H, fx, (0, 0, z), s, 0.8, ks=ks), "FFF")
+    v = (fx * s / z) ** 2
+    coef = math.sqrt(v * v / ((v + ks) ** 2 + 1e-6) + 1e-6)
+    assert np.allclose(fw2["conic_opacity"][0, 3], 0.8 * coef, rtol=1e-4)
+    assert np.allclose(fw2["conic_opacity"][0, 0], 1 / (v + ks), rtol=1e-4)
+
+
+def test_known_answer_two_gaussians_order_median_and_termination():
+    """Two coincident-in-screen Gaussians at different depths: front-to-back order, median selection (pre-blend
+    T > 0.5), contributor counters."""
+    inp = _single(opacity=0.6, scale=0.3)
+    inp["P"] = 2
+    inp["means3D"] = torch.tensor([[0, 0, 6.0], [0, 0, 4.0]])  # index 1 is nearer -> sorted first
+    for k in ("opacities", "tongue_class", "scales", "rotations", "shs"):
+        inp[k] = inp[k].repeat(*([2] + [1] * (inp[k].dim() - 1)))
+    inp["opacities"] = torch.tensor([[0.9], [0.6]])
+    fw = util.oracle_forward(inp, "FTT")
+    assert list(fw["point_list"][:2]) in ([1, 0],) or fw["point_list"][0] == 1
+    py, px = 23, 31
+    c = fw["conic_opacity"]
+    d = fw["means2D"] - np.array([px, py], np.float32)
+    al = [min(0.99, c[i, 3] * math.exp(-0.5 * (c[i, 0] * d[i, 0] ** 2 + c[i, 2] * d[i, 1] ** 2))) for i in (1, 0)]
+    T1 = 1 - al[0]
+    assert np.allclose(fw["alpha"][0, py, px], al[0] + T1 * al[1], rtol=1e-5)
+    assert fw["n_contrib"][0, py, px] == 2
+    # median: the nearer one always (T=1 > .5); the farther only if T after the first is still > .5
+    expect_med = 2 if T1 > 0.5 else 1
+    assert fw["n_contrib"][1, py, px] == expect_med
+    # opaque stack terminates: 40 copies of a 0.9-opacity Gaussian -> T*(1-a) < 1e-4 stops the pixel early
+    inp2 = _single(opacity=0.9, scale=0.3)
+    n = 40
+    inp2["P"] = n
+    inp2["means3D"] = torch.stack([torch.tensor([0, 0, 4.0 + 0.01 * i]) for i in range(n)])
+    for k in ("opacities", "tongue_class", "scales", "rotations", "shs"):
+        inp2[k] = inp2[k].repeat(*([n] + [1] * (inp2[k].dim() - 1)))
+    fw2 = util.oracle_forward(inp2, "FFF")
+    a0 = fw2["conic_opacity"][0, 3] * math.exp(-0.5 * (fw2["conic_opacity"][0, 0] * 0.5))
+    k_stop = 0
+    T = 1.0
+    while T * (1 - a0) >= 1e-4:
+        T *= (1 - a0); k_stop += 1
+    assert fw2["n_contrib"][0, py, px] == k_stop and k_stop < n
+    assert np.allclose(fw2["alpha"][0, py, px], 1 - T, rtol=1e-4)
+
+
+def test_culling_and_empty():
+    inp = _single(pos=(0, 0, 0.19))                                       # z <= 0.2 -> culled (Q8)
+    fw = util.oracle_forward(inp, "FFF")
+    assert fw["radii"][0] == 0 and fw["num_rendered"] == 0 and np.allclose(fw["color"], 1.0)
+    assert not O.mark_visible(inp["means3D"].numpy(), inp["viewmatrix"].numpy(), inp["projmatrix"].numpy())[0]
+    inp = _single(pos=(50.0, 0, 5.0))                                     # far off-screen: rect area 0
+    fw = util.oracle_forward(inp, "FFF")
+    assert fw["radii"][0] == 0 and fw["tiles_touched"][0] == 0
+    assert O.mark_visible(inp["means3D"].numpy(), inp["viewmatrix"].numpy(), inp["projmatrix"].numpy())[0]
+    inp = util.scene_inputs(0, 64, 48)                                     # P = 0
+    fw = util.oracle_forward(inp, "TTT")
+    assert fw["num_rendered"] == 0 and np.allclose(fw["color"], 1.0) and fw["ranges"].sum() == 0
+
+
+# ---------------------------------------------------------------- invariants on a random scene
+def test_binning_invariants_and_blend_identities():
+    inp = util.scene_inputs(3000, 200, 152, scene_seed=4)
+    fw = util.oracle_forward(inp, "TTT")
+    R = fw["num_rendered"]
+    assert R == int(fw["tiles_touched"].sum()) == int(fw["point_offsets"][-1])
+    keys = fw["keys"]
+    mask = (1 << fw["sort_bits"]) - 1
+    assert np.all(np.diff((keys & mask).astype(np.int64)) >= 0)                     # sorted on the key bits
+    assert sorted(fw["keys_unsorted"].tolist()) == sorted(keys.tolist())
+    # ranges partition [0, R) in tile order; empty tiles stay (0, 0)
+    rg = fw["ranges"]
+    nz = rg[rg[:, 1] > rg[:, 0]]
+    assert nz[0, 0] == 0 and nz[-1, 1] == R and np.all(nz[1:, 0] == nz[:-1, 1])
+    for t in np.random.RandomState(0).choice(len(rg), 20):
+        s, e = rg[t]
+        assert np.all((keys[s:e] >> 32) == t)
+        dep = fw["depths"][fw["point_list"][s:e]]
+        assert np.all(np.diff(dep) >= 0)                                             # front to back
+    # blend identities (Q5): colour of an all-white scene = alpha + T_final*bg with T_final = prod(1-a)
+    good = fw["margin"] > 1e-4
+    assert np.all(fw["alpha"] <= 1.0 + 1e-6) and np.all(fw["alpha"] >= 0)
+    nl = np.linalg.norm(fw["normal"], axis=0)
+    hit = fw["n_contrib"][0] > 0
+    assert np.allclose(nl[hit & good], 1.0, atol=1e-4) and np.all(nl[~hit] == 0)
+    assert np.all(fw["n_contrib"][1][hit] <= fw["n_contrib"][0][hit])               # median <= last
+    assert np.all(fw["depth"][0][~hit] == 0)
+
+
+def test_stable_sort_ties_resolve_by_gaussian_index():
+    inp = _single(opacity=0.5, scale=0.3)
+    inp["P"] = 3
+    inp["means3D"] = torch.tensor([[0, 0, 5.0]] * 3)                                  # identical depth bits
+    for k in ("opacities", "tongue_class", "scales", "rotations", "shs"):
+        inp[k] = inp[k].repeat(*([3] + [1] * (inp[k].dim() - 1)))
+    fw = util.oracle_forward(inp, "FFF")
+    s, e = fw["ranges"][fw["ranges"][:, 1] > 0][0]
+    assert list(fw["point_list"][s:e]) == [0, 1, 2]
+
+
+# ---------------------------------------------------------------- independent restatement (values + gradients)
+@pytest.mark.parametrize("variant,tol_img,tol_grad", [("FFF", 1e-5, 1e-3), ("FTT", 5e-4, 3e-3), ("TTT", 5e-4, 3e-3)])
+def test_c_oracle_vs_torch_autograd_restatement(variant, tol_img, tol_grad):
+    """oracle/raster_ref.c (hand-derived backward, fp32) against oracle/torch_raster.py (torch.autograd, fp64).
+    The geometry variants are looser: the C side keeps the reference's truncated eigen-solver (1e-7 absolute
+    thresholds), the torch side uses eigh; FFF does not touch that path."""
+    torch.set_num_threads(8)
+    P, W, H = 1500, 144, 112
+    inp = util.scene_inputs(P, W, H, scene_seed=2, kernel_size=0.3)
+    rc, rd = util.VARIANTS[variant]
+    fw = util.oracle_forward(inp, variant)
+    leaf = lambda t: t.double().clone().requires_grad_(True)
+    m3, op, sc, ro, sh = [leaf(inp[k]) for k in ("means3D", "opacities", "scales", "rotations", "shs")]
+    out = TR.rasterize(inp["bg"].double(), m3, op, sc, ro, sh, inp["viewmatrix"].double(), inp["projmatrix"].double(),
+                       inp["campos"].double(), inp["tanfovx"], inp["tanfovy"], inp["kernel_size"], H, W, 3, rc, rd)
+    assert np.array_equal(out["radii"].numpy(), fw["radii"]) and np.array_equal(out["ids"].numpy(), fw["point_list"])
+    good = fw["margin"] >= 1e-4
+    for k in ("color", "alpha", "depth", "mdepth", "normal", "coord", "mcoord"):
+        if np.abs(fw[k]).max() > 0:
+            assert util.rel_linf(out[k].detach().numpy(), fw[k], good) <= tol_img, k
+    g = S.make_upstream_grads(H, W)
+    if not rc:
+        g["coord"].zero_(); g["mcoord"].zero_()
+    if not rd:
+        g["depth"].zero_(); g["mdepth"].zero_()
+    if not (rc or rd):
+        g["normal"].zero_()
+    # keep ill-conditioned pixels out of the loss on both sides
+    gm = torch.from_numpy(good)
+    for k in g:
+        g[k] = g[k] * gm
+    loss = sum((out[k] * g[k].double()).sum() for k in ("color", "alpha", "depth", "mdepth", "normal", "coord", "mcoord"))
+    loss.backward()
+    bw = util.oracle_backward(inp, fw, g, variant, reference_q1=False)
+    for n, t in (("dL_dmeans3D", m3), ("dL_dopacity", op), ("dL_dscales", sc), ("dL_drotations", ro), ("dL_dsh", sh)):
+        a, b = t.grad.numpy().reshape(bw[n].shape), bw[n]
+        assert np.abs(a - b).max() / np.abs(b).max() <= tol_grad, (n, np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_q1_switch_only_matters_with_kernel_size():
+    """Quirk Q1 feeds only the mip-coefficient gradient: with kernel_size = 0 both settings agree (det0 == det1)."""
+    inp = util.scene_inputs(800, 96, 80, scene_seed=6, kernel_size=0.0)
+    fw = util.oracle_forward(inp, "FTT")
+    g = S.make_upstream_grads(80, 96)
+    a = util.oracle_backward(inp, fw, g, "FTT", reference_q1=True)
+    b = util.oracle_backward(inp, fw, g, "FTT", reference_q1=False)
+    # kernel_size = 0 -> dcoef terms cancel to rounding; the conic-path gradient dominates
+    assert np.abs(a["dL_dscales"] - b["dL_dscales"]).max() <= 2e-3 * np.abs(b["dL_dscales"]).max()
+
+
+# ---------------------------------------------------------------- deformation: pinned by the reference's outputs
+class _A:
+    pass
+
+
+def _load_gold(path):
+    z = np.load(path)
+    args = DR.Args(**{k[4:]: z[k].item() for k in z.files if k.startswith("arg_")})
+    cam = int(z["cfg_cam_no"])
+    return z, args, (None if cam < 0 else cam)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
+def test_deformation_numpy_oracle_matches_reference_goldens(path):
+    z, args, cam = _load_gold(path)
+    sd = {k[3:]: z[k] for k in z.files if k.startswith("sd_")}
+    fin, sub, _ = DR.forward(sd, args, int(z["cfg_D"]), int(z["cfg_max"]), z["in_xyz"], z["in_scales"], z["in_rot"],
+                             z["in_opacity"], z["in_sh"], z["in_emb"], float(z["cfg_time"]), cam, int(z["cfg_iter"]),
+                             int(z["cfg_nde_c"]), int(z["cfg_nde_f"]))
+    for n, a in zip(("xyz", "scales", "rot", "opacity", "sh"), fin):
+        ref = z["out_" + n]
+        assert np.abs(a.reshape(ref.shape) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0), n
+    for n, a in zip(("xyz", "scales", "rot", "opacity", "sh"), sub):
+        ref = z["sub_" + n]
+        assert np.abs(a.reshape(ref.shape) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0), n
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
+def test_deformation_torch_restatement_matches_reference_grads(path):
+    z, args, cam = _load_gold(path)
+    sd = {k[3:]: torch.from_numpy(z[k]).double().requires_grad_(True) for k in z.files if k.startswith("sd_")}
+    b = {n: torch.from_numpy(z["in_" + n]).double().requires_grad_(True) for n in ("xyz", "scales", "rot", "opacity", "sh", "emb")}
+    fin, sub = DT.forward(sd, args, int(z["cfg_D"]), int(z["cfg_max"]), b["xyz"], b["scales"], b["rot"], b["opacity"],
+                          b["sh"], b["emb"], float(z["cfg_time"]), cam, int(z["cfg_iter"]), int(z["cfg_nde_c"]),
+                          int(z["cfg_nde_f"]))
+    ws = [torch.from_numpy(z[f"lossw_{i}"]).double() for i in range(10)]
+    loss = sum((x * w.reshape(x.shape)).sum() for x, w in zip(list(fin) + list(sub), ws))
+    loss.backward()
+    for k, v in sd.items():
+        ref = z["gsd_" + k]
+        if ref.size == 0 or np.abs(ref).max() == 0:
+            continue
+        assert np.abs(v.grad.numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), k
+    for n in b:
+        ref = z["gin_" + n]
+        assert np.abs(b[n].grad.numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-30), n
+
+
+def test_temporal_embed_properties():
+    rng = np.random.RandomState(1)
+    w = rng.randn(25, 64).astype(np.float32)
+    # t on a grid node of the un-resized table returns that row
+    assert np.allclose(DR.temporal_embed(w, 0.5, 25), w[12], atol=1e-5)
+    assert np.allclose(DR.temporal_embed(w, 0.0, 9), w[0], atol=1e-6)
+    assert np.allclose(DR.temporal_embed(w, 1.0, 9), w[24], atol=1e-5)
+    # reflection padding: t and -t, 1+d and 1-d coincide
+    assert np.allclose(DR.temporal_embed(w, -0.2, 9), DR.temporal_embed(w, 0.2, 9), atol=1e-5)
+    assert np.allclose(DR.temporal_embed(w, 1.2, 9), DR.temporal_embed(w, 0.8, 9), atol=1e-5)
+    rows, coefs = DR.temporal_embed_lerp_coefs(25, 0.37, 9)
+    assert abs(sum(coefs) - 1) < 1e-9
+    assert np.allclose(sum(c * w[r] for r, c in zip(rows, coefs)), DR.temporal_embed(w, 0.37, 9), atol=1e-4)
+    assert DR.int_lininterp(5000, 30, 150, 10000) == 90 and DR.int_lininterp(99999, 30, 150, 10000) == 150
+
+
+# ---------------------------------------------------------------- host logic / surface / library
+def test_library_exports_every_declared_symbol():
+    from ed3dgs_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ed3dgs.h")).read()
+    declared = set(re.findall(r"\b(ed3dgs_[a-z_0-9]+)\s*\(", hdr)) - {"ed3dgs_alloc_fn"}
+    L = _lib.lib()
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) >= declared - {"ed3dgs_deform_cfg", "ed3dgs_state_view"}
+    assert L.ed3dgs_abi_version() == 1
+    assert L.ed3dgs_backward_workspace_bytes(1000, 0) >= 1000 * 64
+
+
+def test_python_surface_matches_reference_names_and_errors():
+    import diff_gaussian_rasterization as dgr
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "kernel_size", "bg", "scale_modifier", "viewmatrix",
+        "projmatrix", "sh_degree", "campos", "prefiltered", "require_depth", "require_coord", "debug")
+    for n in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "integrate_gaussians_to_points"):
+        assert hasattr(dgr._C, n)
+    rs = dgr.GaussianRasterizationSettings(8, 8, 1.0, 1.0, 0.0, torch.ones(3), 1.0, torch.eye(4), torch.eye(4), 3,
+                                           torch.zeros(3), False, True, False, False)
+    r = dgr.GaussianRasterizer(rs)
+    x = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one"):
+        r(x, x, torch.zeros(4, 1), torch.zeros(4, 1))
+    with pytest.raises(Exception, match="exactly one"):
+        r(x, x, torch.zeros(4, 1), torch.zeros(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        dgr._C.rasterize_gaussians(torch.ones(3), torch.zeros(12), torch.Tensor([]), torch.zeros(4, 1), torch.zeros(4, 1),
+                                   torch.zeros(4, 3), torch.zeros(4, 4), 1.0, torch.Tensor([]), torch.eye(4), torch.eye(4),
+                                   1.0, 1.0, 0.0, 8, 8, torch.zeros(4, 16, 3), 3, torch.zeros(3), False, True, True, False)
+    with pytest.raises(RuntimeError, match="GPU"):  # no CPU fallback: fails loudly
+        r(x, x, torch.zeros(4, 1), torch.zeros(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.zeros(4, 3), rotations=torch.zeros(4, 4))
+    import gaussian_renderer as gr
+    import inspect
+    sig = list(inspect.signature(gr.render).parameters)
+    assert sig == ["viewpoint_camera", "pc", "pipe", "bg_color", "kernel_size", "scaling_modifier", "require_coord",
+                   "require_depth", "override_color", "cam_no", "iter", "train_coarse", "num_down_emb_c",
+                   "num_down_emb_f", "disable_filter3D"]
+    assert list(inspect.signature(gr.render_tongue).parameters) == sig
+
+
+def test_deform_network_state_dict_keys_and_row_counts():
+    from scene.deformation import deform_network
+    a = DR.Args()
+    net = deform_network(D=1, W=64, args=a)
+    keys = set(net.state_dict())
+    want = {"weight", "offsets"}
+    for s in "cf":
+        want |= {f"feature_out_{s}.0.weight", f"feature_out_{s}.0.bias"}
+        for h in ("pos", "scales", "rotations", "opacity", "rgb"):
+            want |= {f"{h}_deform_{s}.{i}.{p}" for i in (1, 3) for p in ("weight", "bias")}
+    assert keys == want
+    assert net.weight.shape == (150, 256) and net.offsets.shape == (30, 1)
+    assert net.rgb_deform_c[3].weight.shape == (48, 64) and net.feature_out_f[0].weight.shape == (64, 288)
+    assert net._row_counts(5000, 30, 30) == DR.row_counts(a, 5000, 150, 30, 30)
+    a2 = DR.Args(use_coarse_temporal_embedding=True, no_c2f_temporal_embedding=True)
+    assert deform_network(D=1, W=32, args=a2)._row_counts(10, 7, 9) == (7, 150)
+    assert len(net._flat_stage("c")) == 64 * 288 + 64 + 5 * (64 * 64 + 64) + (3 + 3 + 4 + 1 + 48) * (64 + 1)
+    assert [n for n, _ in net.named_parameters() if n == "offsets"] and all(p is not net.offsets for p in net.get_mlp_parameters())
+
+
+def test_synthetic_camera_matrices():
+    cam = S.make_cameras(3, 640, 360)[1]
+    V = cam.world_view_transform
+    assert torch.allclose(V[:3, :3] @ V[:3, :3].t(), torch.eye(3), atol=1e-5)                # rotation block
+    c = torch.cat([cam.camera_center, torch.ones(1)])
+    assert torch.allclose(c @ V, torch.tensor([0.0, 0, 0, 1]), atol=1e-5)                    # centre maps to origin
+    o = torch.tensor([0.0, 0, 0, 1]) @ V
+    assert abs(float(o[0])) < 1e-5 and abs(float(o[1])) < 1e-5 and float(o[2]) > 3.5          # looks at the origin
+    assert torch.allclose(cam.full_proj_transform, V @ cam.projection_matrix, atol=1e-6)
