@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -307,7 +308,7 @@ __device__ __forceinline__ void load_emb_slots(const float *__restrict__ emb, in
 // forward: one wave per strip of 32 Gaussians, both stages, five heads, register resident
 // ------------------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ void __launch_bounds__(256) deform_forward_kernel(DeformDev d)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_forward_kernel(DeformDev d)
 {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -355,31 +356,33 @@ __global__ void __launch_bounds__(256) deform_forward_kernel(DeformDev d)
                 }
                 for (int k = 0; k < NHEAD; k++) {
                     if (!d.enabled[k]) continue;
-                    float z[NT][16];
+                    // head hidden tile by tile: z_nt = relu(b2 + W2[nt,:] a) is consumed at once as k-tile nt of the
+                    // output GEMM, so only one 32x32 z tile is live
+                    f32x16 y[OTMAX];
 #pragma unroll
+                    for (int ot = 0; ot < OTMAX; ot++) y[ot] = bias_acc(fr + d.fl.B3 + (size_t)k * OTMAX * 32, ot, h);
+                    const int nout = d.ot[k];
+#pragma unroll 1
                     for (int nt = 0; nt < NT; nt++) {
                         f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
                         acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
+                        float z[1][16];
 #pragma unroll
-                        for (int r = 0; r < 16; r++) z[nt][r] = fmaxf(acc[r], 0.f);
+                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                        y[0] = gemm_tile<1>(fr + d.fl.F3 + ((((size_t)k * OTMAX + 0) * NT) + nt) * 1024, z, y[0], lane);
+                        if (nout > 1)
+                            y[1] = gemm_tile<1>(fr + d.fl.F3 + ((((size_t)k * OTMAX + 1) * NT) + nt) * 1024, z, y[1], lane);
                     }
                     const float hc = d.hc[k];
-                    for (int ot = 0; ot < d.ot[k]; ot++) {
-                        f32x16 y = bias_acc(fr + d.fl.B3 + (size_t)k * OTMAX * 32, ot, h);
-                        y = gemm_tile<NT>(fr + d.fl.F3 + (((size_t)k * OTMAX + ot) * NT) * 1024, z, y, lane);
-                        if (k == 0) { if (h == 0) { cx[0] += y[0] * hc; cx[1] += y[1] * hc; cx[2] += y[2] * hc; } }
-                        else if (k == 1) { if (h == 0) { cs[0] += y[0] * hc; cs[1] += y[1] * hc; cs[2] += y[2] * hc; } }
-                        else if (k == 2) { if (h == 0) { cr[0] += y[0] * hc; cr[1] += y[1] * hc; cr[2] += y[2] * hc; cr[3] += y[3] * hc; } }
-                        else if (k == 3) { if (h == 0) co += y[0] * hc; }
-                        else {
-                            if (ot == 0) {
+                    if (k == 0) { if (h == 0) { cx[0] += y[0][0] * hc; cx[1] += y[0][1] * hc; cx[2] += y[0][2] * hc; } }
+                    else if (k == 1) { if (h == 0) { cs[0] += y[0][0] * hc; cs[1] += y[0][1] * hc; cs[2] += y[0][2] * hc; } }
+                    else if (k == 2) { if (h == 0) { cr[0] += y[0][0] * hc; cr[1] += y[0][1] * hc; cr[2] += y[0][2] * hc; cr[3] += y[0][3] * hc; } }
+                    else if (k == 3) { if (h == 0) co += y[0][0] * hc; }
+                    else {
 #pragma unroll
-                                for (int r = 0; r < 16; r++) csh[r] += y[r] * hc;
-                            } else {
+                        for (int r = 0; r < 16; r++) csh[r] += y[0][r] * hc;
 #pragma unroll
-                                for (int r = 0; r < 8; r++) csh[16 + r] += y[r] * hc;
-                            }
-                        }
+                        for (int r = 0; r < 8; r++) csh[16 + r] += y[1][r] * hc;
                     }
                 }
             }
@@ -416,7 +419,7 @@ __device__ __forceinline__ void store_tile_rows(float *__restrict__ M, int ld, i
 }
 
 template <int NT>
-__global__ void __launch_bounds__(256) deform_dgrad_kernel(DeformDev d)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_dgrad_kernel(DeformDev d)
 {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -463,15 +466,6 @@ __global__ void __launch_bounds__(256) deform_dgrad_kernel(DeformDev d)
                 for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
             for (int k = 0; k < NHEAD; k++) {
                 if (!d.enabled[k]) continue;
-                float z[NT][16];
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-                    acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) z[nt][r] = fmaxf(acc[r], 0.f);
-                    if (gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[nt]);
-                }
                 // B operand of the head-output backward: gy[ot][kk] = hc * g_head[g][ot*32 + f(kk,h)]
                 const float hc = d.hc[k];
                 const int nk = d.nk[k];
@@ -502,25 +496,42 @@ __global__ void __launch_bounds__(256) deform_dgrad_kernel(DeformDev d)
                         gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
                     }
                 }
-                // g_z = (W3^T g_y) masked by z > 0 ; stored ; g_a += W2^T g_z
-#pragma unroll
+                // one 32-feature tile of the head hidden at a time: recompute z_nt, store relu(z_nt), form
+                // g_z_nt = (W3^T g_y)_nt masked by z_nt > 0, store it, and push it through W2^T into g_a
+#pragma unroll 1
                 for (int nt = 0; nt < NT; nt++) {
+                    float z[1][16];
+                    {
+                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                        acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
+#pragma unroll
+                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                    }
+                    if (gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[r] = 0.f;
-                    for (int ot = 0; ot < d.ot[k]; ot++) {
-                        const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX + ot) * 16) * 64;
+                    if (k < 4) {  // 3 / 3 / 4 / 1 outputs: only the first k-slots of half 0 are non-zero
+                        const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX) * 16) * 64;
 #pragma unroll
-                        for (int kk = 0; kk < 16; kk++)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], ot == 0 ? gy[0][kk] : gy[1][kk], acc, 0, 0, 0);
+                        for (int kk = 0; kk < 4; kk++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++) {
+                            const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX + ot) * 16) * 64;
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[ot][kk], acc, 0, 0, 0);
+                        }
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; r++) z[nt][r] = z[nt][r] > 0.f ? acc[r] : 0.f;
-                    if (gvalid) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[nt]);
-                }
+                    for (int r = 0; r < 16; r++) z[0][r] = z[0][r] > 0.f ? acc[r] : 0.f;
+                    if (gvalid) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    ga[nt] = gemm_tile<NT>(fr + d.fl.F2T + (((size_t)k * NT + nt) * NT) * 1024, z, ga[nt], lane);
+                    for (int it = 0; it < NT; it++)
+                        ga[it] = gemm_tile<1>(fr + d.fl.F2T + ((((size_t)k * NT + it) * NT) + nt) * 1024, z, ga[it], lane);
+                }
             }
             // g_hid = g_a masked by hid > 0 ; stored ; g_emb += W1[:, TD:]^T g_hid
             float gh[NT][16];
@@ -556,49 +567,140 @@ struct WgradArgs {
     WgradJob job[MAXJOBS];
 };
 
-__global__ void __launch_bounds__(64) deform_wgrad_kernel(WgradArgs a)
+// Block = 4 waves computes the WHOLE dW of one job for one range of Gaussians: slabs of 32 rows of G and X are staged
+// once into LDS (row-major, exactly the MFMA operand order: lane c of half h reads row 2kk+h, column tile*32+c), every
+// wave owns up to 4 of the job's 32x32 tiles.  Each G / X element is read from HBM once per job.
+constexpr int WG_ROWS = 32;
+__global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
 {
-    const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
-    const int tile = blockIdx.x, ks = blockIdx.y;
-    int j = 0;
-    while (j + 1 < a.njobs && tile >= a.tile_begin[j + 1]) j++;
-    const WgradJob &J = a.job[j];
-    const int ntn = (J.N + 31) / 32;
-    const int lt = tile - a.tile_begin[j];
-    const int mt = lt / ntn, nt = lt % ntn;
-    const int m = mt * 32 + c, n = nt * 32 + c;
-    const bool mok = m < J.M, nok = n < J.N;
-    const int p0 = ks * a.chunk, p1 = min(a.P, p0 + a.chunk);
-    f32x16 acc;
+    extern __shared__ float wg_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const WgradJob &J = a.job[blockIdx.x];
+    const int Mp = (J.M + 31) & ~31, Np = (J.N + 31) & ~31;   // padded extents (LDS row strides)
+    const int mt_n = Mp / 32, nt_n = Np / 32, ntiles = mt_n * nt_n;
+    float *Gs[2] = {wg_lds, wg_lds + WG_ROWS * (Mp + Np)};
+    float *Xs[2] = {Gs[0] + WG_ROWS * Mp, Gs[1] + WG_ROWS * Mp};
+    const int p0 = blockIdx.y * a.chunk, p1 = min(a.P, p0 + a.chunk);
+    if (p0 >= p1) return;
+    const int nslab = (p1 - p0 + WG_ROWS - 1) / WG_ROWS;
+
+    // tiles owned by this wave: t = wave, wave+4, ... (at most 4 for a 128x128 job)
+    // tile ownership: the job's tiles form an mt_n x nt_n grid; a wave owns a 2 x 2 patch (or what exists of it), so a
+    // k-step costs 2 A reads + 2 B reads for up to 4 MFMAs
+    const int pm = (mt_n + 1) / 2, pn = (nt_n + 1) / 2;      // patches along m / n
+    int my_mt[4], my_nt[4];
+    bool mine[4];
+    {
+        const int patch = wave;                                // patches are dealt wave, wave + 4, ... (<= 4 for 128x128)
+        const int pmi = patch / pn, pni = patch % pn;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    float bsum = 0.f;
-    for (int pb = p0; pb < p1; pb += 8) {  // wave-uniform trip count: 8 rows = 4 MFMA k-steps of 2
-        float av[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int pp = pb + h + 2 * u;
-            const bool ok = pp < p1;
-            float gval = 0.f;
-            if (ok && mok) { gval = J.G ? J.G[(size_t)pp * J.ldg + m] : 0.f; if (J.G2) gval += J.G2[(size_t)pp * J.ldg + m]; gval *= J.gscale; }
-            av[u] = gval;
-            bv[u] = (ok && nok) ? J.X[(size_t)pp * J.ldx + n] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-            bsum += av[u];
+        for (int q = 0; q < 4; q++) {
+            my_mt[q] = 2 * pmi + (q >> 1);
+            my_nt[q] = 2 * pni + (q & 1);
+            mine[q] = (patch < pm * pn) && my_mt[q] < mt_n && my_nt[q] < nt_n;
+            if (!mine[q]) { my_mt[q] = 0; my_nt[q] = 0; }
         }
     }
+    (void)ntiles;
+    f32x16 acc[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int mi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (mi < J.M && nok) atomicAdd(J.dW + (size_t)mi * J.ldd + n, acc[r]);
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+    float bsum = 0.f;  // thread tid < M accumulates column tid of G
+
+    // staging: the slab of rows [r0, r0+32) of G (scaled, optional second addend) and of X goes global -> registers
+    // (issued before the MFMA loop of the current slab) -> LDS (after it), double buffered.
+    const bool gvec = (J.ldg % 4 == 0) && (J.M % 4 == 0);
+    const bool xvec = (J.ldx % 4 == 0) && (J.N % 4 == 0);
+    const int gpr = Mp / 4, xpr = Np / 4;          // float4 per row
+    int g_r[4], g_c[4], x_r[4], x_c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = tid + 256 * i;
+        g_r[i] = e / gpr; g_c[i] = (e % gpr) * 4;
+        x_r[i] = e / xpr; x_c[i] = (e % xpr) * 4;
     }
-    if (J.db && nt == 0) {
-        bsum += __shfl_xor(bsum, 32);
-        if (h == 0 && mok) atomicAdd(J.db + m, bsum);
+    float4 gv[4], xv[4];
+    auto load_regs = [&](int slab) {
+        const int r0 = p0 + slab * WG_ROWS;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            gv[i] = make_float4(0, 0, 0, 0);
+            xv[i] = make_float4(0, 0, 0, 0);
+            if (gvec && g_r[i] < WG_ROWS && r0 + g_r[i] < p1 && g_c[i] < J.M) {
+                const size_t o = (size_t)(r0 + g_r[i]) * J.ldg + g_c[i];
+                float4 v = *reinterpret_cast<const float4 *>(J.G + o);
+                if (J.G2) { const float4 w2 = *reinterpret_cast<const float4 *>(J.G2 + o); v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w; }
+                gv[i] = make_float4(v.x * J.gscale, v.y * J.gscale, v.z * J.gscale, v.w * J.gscale);
+            }
+            if (xvec && x_r[i] < WG_ROWS && r0 + x_r[i] < p1 && x_c[i] < J.N)
+                xv[i] = *reinterpret_cast<const float4 *>(J.X + (size_t)(r0 + x_r[i]) * J.ldx + x_c[i]);
+        }
+    };
+    auto store_lds = [&](int slab, int buf) {
+        const int r0 = p0 + slab * WG_ROWS;
+        float *g = Gs[buf], *x = Xs[buf];
+        if (gvec) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (g_r[i] < WG_ROWS) *reinterpret_cast<float4 *>(g + g_r[i] * Mp + g_c[i]) = gv[i];
+        } else {  // narrow upstream gradients ([P][3], [P][1], ...): scalar path, a few elements per thread
+            for (int e = tid; e < WG_ROWS * Mp; e += 256) {
+                const int r = e / Mp, cc = e % Mp, p = r0 + r;
+                float v = 0.f;
+                if (p < p1 && cc < J.M) { v = J.G[(size_t)p * J.ldg + cc]; if (J.G2) v += J.G2[(size_t)p * J.ldg + cc]; v *= J.gscale; }
+                g[r * Mp + cc] = v;
+            }
+        }
+        if (xvec) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (x_r[i] < WG_ROWS) *reinterpret_cast<float4 *>(x + x_r[i] * Np + x_c[i]) = xv[i];
+        } else {
+            for (int e = tid; e < WG_ROWS * Np; e += 256) {
+                const int r = e / Np, cc = e % Np, p = r0 + r;
+                x[r * Np + cc] = (p < p1 && cc < J.N) ? J.X[(size_t)p * J.ldx + cc] : 0.f;
+            }
+        }
+    };
+
+    load_regs(0);
+    store_lds(0, 0);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; slab++) {
+        const int buf = slab & 1;
+        if (slab + 1 < nslab) load_regs(slab + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next slab's global loads in flight under this slab's MFMAs
+        const float *g = Gs[buf], *x = Xs[buf];
+#pragma unroll 4
+        for (int kk = 0; kk < WG_ROWS / 2; kk++) {
+            const int row = 2 * kk + h;
+            const float a0 = g[row * Mp + my_mt[0] * 32 + c], a1 = g[row * Mp + my_mt[2] * 32 + c];
+            const float b0 = x[row * Np + my_nt[0] * 32 + c], b1 = x[row * Np + my_nt[1] * 32 + c];
+            if (mine[0]) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            if (mine[1]) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+            if (mine[2]) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
+            if (mine[3]) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
+        }
+        if (J.db && tid < J.M) {
+#pragma unroll 8
+            for (int r = 0; r < WG_ROWS; r++) bsum += g[r * Mp + tid];
+        }
+        if (slab + 1 < nslab) store_lds(slab + 1, buf ^ 1);
+        __syncthreads();
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (!mine[q]) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mi = my_mt[q] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ni = my_nt[q] * 32 + c;
+            if (mi < J.M && ni < J.N) atomicAdd(J.dW + (size_t)mi * J.ldd + ni, acc[q][r]);
+        }
+    }
+    if (J.db && tid < J.M) atomicAdd(J.db + tid, bsum);
 }
 
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
@@ -836,11 +938,19 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     });
     if (!check_hip(hipGetLastError(), "deform dgrad")) return ED3DGS_ERR_HIP;
 
-    // weight gradients
-    WgradArgs wa;
-    std::memset(&wa, 0, sizeof wa);
-    wa.P = cfg->P;
-    int nj = 0, tiles = 0;
+    // weight gradients: jobs of at most 128 x 128 (one block tile), launched in batches of MAXJOBS
+    std::vector<WgradJob> jobs;
+    auto add_job = [&](const float *G, const float *G2, int ldg, int M, float gscale, const float *X, int ldx, int N,
+                       float *dW, int ldd, float *db) {
+        for (int m0 = 0; m0 < M; m0 += 128)
+            for (int n0 = 0; n0 < N; n0 += 128) {
+                WgradJob J;
+                J.G = G + m0; J.G2 = G2 ? G2 + m0 : nullptr; J.ldg = ldg; J.M = std::min(128, M - m0); J.gscale = gscale;
+                J.X = X + n0; J.ldx = ldx; J.N = std::min(128, N - n0);
+                J.dW = dW + (size_t)m0 * ldd + n0; J.ldd = ldd; J.db = (db && n0 == 0) ? db + m0 : nullptr;
+                jobs.push_back(J);
+            }
+    };
     const bool both = cfg->use_stage[0] && cfg->use_stage[1];
     for (int st = 0; st < 2; st++) {
         if (!cfg->use_stage[st]) continue;
@@ -849,37 +959,30 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         for (int k = 0; k < NHEAD; k++) {
             if (!d.enabled[k]) continue;
             const float *G = add_out ? gg[k] : nullptr, *G2 = add_sub ? gsub[k] : nullptr;
-            if (G || G2) {  // dW3 / db3 from the upstream gradient of the head's output
-                WgradJob &J = wa.job[nj];
-                if (!G) { G = G2; G2 = nullptr; }
-                J.G = G; J.G2 = G2; J.ldg = d.nk[k]; J.M = d.nk[k]; J.gscale = d.hc[k];
-                J.X = w.ZR[st] + k * PW; J.ldx = cfg->W; J.N = cfg->W;
-                J.dW = gparams[st] + pl.W3[k]; J.ldd = cfg->W; J.db = gparams[st] + pl.b3[k];
-                wa.tile_begin[nj] = tiles; tiles += ((J.M + 31) / 32) * ((J.N + 31) / 32); nj++;
-            }
-            {   // dW2 / db2
-                WgradJob &J = wa.job[nj];
-                J.G = w.GZ[st] + k * PW; J.G2 = nullptr; J.ldg = cfg->W; J.M = cfg->W; J.gscale = 1.f;
-                J.X = w.A[st]; J.ldx = cfg->W; J.N = cfg->W;
-                J.dW = gparams[st] + pl.W2[k]; J.ldd = cfg->W; J.db = gparams[st] + pl.b2[k];
-                wa.tile_begin[nj] = tiles; tiles += ((J.M + 31) / 32) * ((J.N + 31) / 32); nj++;
-            }
+            if (!G) { G = G2; G2 = nullptr; }
+            if (G)  // dW3 / db3 from the upstream gradient of the head's output
+                add_job(G, G2, d.nk[k], d.nk[k], d.hc[k], w.ZR[st] + k * PW, cfg->W, cfg->W, gparams[st] + pl.W3[k],
+                        cfg->W, gparams[st] + pl.b3[k]);
+            add_job(w.GZ[st] + k * PW, nullptr, cfg->W, cfg->W, 1.f, w.A[st], cfg->W, cfg->W, gparams[st] + pl.W2[k],
+                    cfg->W, gparams[st] + pl.b2[k]);  // dW2 / db2
         }
-        {   // dW1[:, TD:] and db1 (= g_hb)
-            WgradJob &J = wa.job[nj];
-            J.G = w.GHID[st]; J.G2 = nullptr; J.ldg = cfg->W; J.M = cfg->W; J.gscale = 1.f;
-            J.X = embedding; J.ldx = cfg->E; J.N = cfg->E;
-            J.dW = gparams[st] + pl.W1 + cfg->TD; J.ldd = cfg->TD + cfg->E; J.db = gparams[st] + pl.b1;
-            wa.tile_begin[nj] = tiles; tiles += ((J.M + 31) / 32) * ((J.N + 31) / 32); nj++;
-        }
+        add_job(w.GHID[st], nullptr, cfg->W, cfg->W, 1.f, embedding, cfg->E, cfg->E, gparams[st] + pl.W1 + cfg->TD,
+                cfg->TD + cfg->E, gparams[st] + pl.b1);  // dW1[:, TD:] and db1 (= g_hb)
     }
-    wa.njobs = nj; wa.tile_begin[nj] = tiles;
-    int ksplit = std::max(1, std::min(256, (256 * 16 + tiles - 1) / std::max(tiles, 1)));
-    int chunk = ((cfg->P + ksplit - 1) / ksplit + 7) & ~7;
-    if (chunk < 8) chunk = 8;
+    const int nj_total = (int)jobs.size();
+    // one resident round of blocks (2 per CU at 64 KB of LDS each)
+    int ksplit = std::max(1, std::min((cfg->P + 255) / 256, (256 * 2) / std::max(nj_total, 1)));
+    int chunk = ((cfg->P + ksplit - 1) / ksplit + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
     ksplit = (cfg->P + chunk - 1) / chunk;
-    wa.ksplit = ksplit; wa.chunk = chunk;
-    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(tiles, ksplit), dim3(64), 0, s, wa);
+    const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
+    for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
+        WgradArgs wa;
+        std::memset(&wa, 0, sizeof wa);
+        wa.P = cfg->P; wa.ksplit = ksplit; wa.chunk = chunk;
+        wa.njobs = std::min(MAXJOBS, nj_total - j0);
+        for (int q = 0; q < wa.njobs; q++) wa.job[q] = jobs[j0 + q];
+        hipLaunchKernelGGL(deform_wgrad_kernel, dim3(wa.njobs, ksplit), dim3(256), wg_lds, s, wa);
+    }
     if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
 
     FrameBwdArgs fb;
