@@ -574,12 +574,13 @@ constexpr int WG_ROWS = 32;
 __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
 {
     extern __shared__ float wg_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile ownership branches stay scalar
     const WgradJob &J = a.job[blockIdx.x];
     const int Mp = (J.M + 31) & ~31, Np = (J.N + 31) & ~31;   // padded extents (LDS row strides)
     const int mt_n = Mp / 32, nt_n = Np / 32, ntiles = mt_n * nt_n;
-    float *Gs[2] = {wg_lds, wg_lds + WG_ROWS * (Mp + Np)};
-    float *Xs[2] = {Gs[0] + WG_ROWS * Mp, Gs[1] + WG_ROWS * Mp};
+    // two LDS buffers, addressed by offset into the one shared array (keeps the accesses in the LDS address space)
+    const int buf_floats = WG_ROWS * (Mp + Np), x_off = WG_ROWS * Mp;
     const int p0 = blockIdx.y * a.chunk, p1 = min(a.P, p0 + a.chunk);
     if (p0 >= p1) return;
     const int nslab = (p1 - p0 + WG_ROWS - 1) / WG_ROWS;
@@ -621,30 +622,36 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
         g_r[i] = e / gpr; g_c[i] = (e % gpr) * 4;
         x_r[i] = e / xpr; x_c[i] = (e % xpr) * 4;
     }
-    float4 gv[4], xv[4];
+    // loads are issued raw (addresses clamped into the job's range, no arithmetic on the result) so that nothing waits
+    // for them before the MFMA loop; masking, the optional second addend and the scale are applied at LDS-store time
+    float4 gv[4], g2v[4], xv[4];
+    const bool has_g2 = J.G2 != nullptr;
     auto load_regs = [&](int slab) {
         const int r0 = p0 + slab * WG_ROWS;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            gv[i] = make_float4(0, 0, 0, 0);
-            xv[i] = make_float4(0, 0, 0, 0);
-            if (gvec && g_r[i] < WG_ROWS && r0 + g_r[i] < p1 && g_c[i] < J.M) {
-                const size_t o = (size_t)(r0 + g_r[i]) * J.ldg + g_c[i];
-                float4 v = *reinterpret_cast<const float4 *>(J.G + o);
-                if (J.G2) { const float4 w2 = *reinterpret_cast<const float4 *>(J.G2 + o); v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w; }
-                gv[i] = make_float4(v.x * J.gscale, v.y * J.gscale, v.z * J.gscale, v.w * J.gscale);
+            if (gvec) {
+                const size_t o = (size_t)min(r0 + g_r[i], p1 - 1) * J.ldg + min(g_c[i], J.M - 4);
+                gv[i] = *reinterpret_cast<const float4 *>(J.G + o);
+                if (has_g2) g2v[i] = *reinterpret_cast<const float4 *>(J.G2 + o);
             }
-            if (xvec && x_r[i] < WG_ROWS && r0 + x_r[i] < p1 && x_c[i] < J.N)
-                xv[i] = *reinterpret_cast<const float4 *>(J.X + (size_t)(r0 + x_r[i]) * J.ldx + x_c[i]);
+            if (xvec) xv[i] = *reinterpret_cast<const float4 *>(J.X + (size_t)min(r0 + x_r[i], p1 - 1) * J.ldx + min(x_c[i], J.N - 4));
         }
     };
     auto store_lds = [&](int slab, int buf) {
         const int r0 = p0 + slab * WG_ROWS;
-        float *g = Gs[buf], *x = Xs[buf];
+        float *g = wg_lds + buf * buf_floats, *x = wg_lds + buf * buf_floats + x_off;
         if (gvec) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (g_r[i] < WG_ROWS) *reinterpret_cast<float4 *>(g + g_r[i] * Mp + g_c[i]) = gv[i];
+            for (int i = 0; i < 4; i++) {
+                if (g_r[i] < WG_ROWS) {
+                    float4 v = gv[i];
+                    if (has_g2) { v.x += g2v[i].x; v.y += g2v[i].y; v.z += g2v[i].z; v.w += g2v[i].w; }
+                    const bool ok = (r0 + g_r[i] < p1) && (g_c[i] < J.M);
+                    const float sc = ok ? J.gscale : 0.f;
+                    *reinterpret_cast<float4 *>(g + g_r[i] * Mp + g_c[i]) = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+                }
+            }
         } else {  // narrow upstream gradients ([P][3], [P][1], ...): scalar path, a few elements per thread
             for (int e = tid; e < WG_ROWS * Mp; e += 256) {
                 const int r = e / Mp, cc = e % Mp, p = r0 + r;
@@ -655,8 +662,13 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
         }
         if (xvec) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (x_r[i] < WG_ROWS) *reinterpret_cast<float4 *>(x + x_r[i] * Np + x_c[i]) = xv[i];
+            for (int i = 0; i < 4; i++) {
+                if (x_r[i] < WG_ROWS) {
+                    const bool ok = (r0 + x_r[i] < p1) && (x_c[i] < J.N);
+                    const float4 v = xv[i];
+                    *reinterpret_cast<float4 *>(x + x_r[i] * Np + x_c[i]) = ok ? v : make_float4(0, 0, 0, 0);
+                }
+            }
         } else {
             for (int e = tid; e < WG_ROWS * Np; e += 256) {
                 const int r = e / Np, cc = e % Np, p = r0 + r;
@@ -665,14 +677,15 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
         }
     };
 
+    // software pipeline: registers hold slab s+1 while slab s is multiplied out of LDS; the loads of slab s+2 are issued
+    // right after the barrier that publishes slab s+1, so they fly under the next MFMA loop
     load_regs(0);
     store_lds(0, 0);
     __syncthreads();
+    if (nslab > 1) load_regs(1);
     for (int slab = 0; slab < nslab; slab++) {
         const int buf = slab & 1;
-        if (slab + 1 < nslab) load_regs(slab + 1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the next slab's global loads in flight under this slab's MFMAs
-        const float *g = Gs[buf], *x = Xs[buf];
+        const float *g = wg_lds + buf * buf_floats, *x = wg_lds + buf * buf_floats + x_off;
 #pragma unroll 4
         for (int kk = 0; kk < WG_ROWS / 2; kk++) {
             const int row = 2 * kk + h;
@@ -689,6 +702,7 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
         }
         if (slab + 1 < nslab) store_lds(slab + 1, buf ^ 1);
         __syncthreads();
+        if (slab + 2 < nslab) load_regs(slab + 2);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
