@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -88,6 +89,7 @@ struct DeformDev {
     const float *g[5], *gs[5];
     float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
     float *g_emb;
+    int ablate;  // diagnostic builds only: bit mask of phases to skip (timing experiments; results are then wrong)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -553,6 +555,345 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// fused backward (W <= 128): head-specialised blocks.
+//   P1 deform_bwd_head_kernel : block = (row group, head k, stage s), 4 waves = 4 strips of 32 Gaussians per iteration.
+//      Recomputes a = relu(hid) and z_k, forms g_z_k in registers, and accumulates dW3_k = g_y^T relu(z_k) and
+//      dW2_k = g_z_k^T a ON CHIP: the register tiles (feature on the register, Gaussian on the lane) are transposed
+//      through LDS ([row][feature], row stride 132 floats -> conflict-free b128 writes and b32 operand reads) so that
+//      the Gaussian index becomes the MFMA k index; every wave owns a 2x2 patch of dW2_k (and <= 2 tiles of dW3_k) in
+//      accumulator registers for the whole kernel and flushes once.  Only g_a_k = W2_k^T g_z_k leaves the chip
+//      (512 B per Gaussian per head instead of the 12 x 512 B the generic path stores and re-reads).
+//   P2 deform_bwd_trunk_kernel: sums the five g_a_k, masks with a > 0, accumulates dW1[:, TD:] and db1 the same way and
+//      writes dL/d embedding.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int FB_LD = 132;     // LDS row stride (floats) of the transposed tiles
+constexpr int FB_ROWS = 128;   // Gaussians per block iteration (4 waves x 32)
+
+__device__ __forceinline__ void lds_store_tile_T(float *__restrict__ base, int row, int nt, int h, const float (&v)[16])
+{
+    float4 *p = reinterpret_cast<float4 *>(base + row * FB_LD + nt * 32 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; q++) p[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_bwd_head_kernel(DeformDev d, float *GA0, float *GA1, float *gp0, float *gp1, ParamLayout pl)
+{
+    extern __shared__ float fb_lds[];
+    float *A_T = fb_lds;                         // [128][132]  a^T
+    float *Z_T = fb_lds + FB_ROWS * FB_LD;       // [128][132]  relu(z)^T, then g_z^T
+    const int s = blockIdx.z, k = blockIdx.y;
+    if (!d.use_stage[s] || !d.enabled[k]) return;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *fr = d.frag[s];
+    float *GA = (s == 0 ? GA0 : GA1) + (size_t)k * d.P * d.W;
+    float *gp = (s == 0 ? gp0 : gp1);
+    const int shw = 3 * d.n_sh;
+    const bool both = d.use_stage[0] && d.use_stage[1];
+    const bool add_sub = (s == 0), add_out = (s == 1) || both || !d.use_stage[1];
+    const float *gA = add_out ? d.g[k] : nullptr, *gB = add_sub ? d.gs[k] : nullptr;
+    const float hc = d.hc[k];
+    const int nk = d.nk[k], nout = d.ot[k];
+    const int n_iter = (d.P + FB_ROWS - 1) / FB_ROWS;
+
+    // tile ownership
+    //  dW2_k: NT x NT tiles, 2x2 patch per wave (NT = 4), 1 tile per wave (NT = 2), wave 0 only (NT = 1)
+    constexpr int PM = (NT + 1) / 2;
+    const bool w2_on = wave < PM * PM;
+    const int w2_m0 = 2 * (wave / PM), w2_n0 = 2 * (wave % PM);
+    //  dW3_k: nout x NT tiles, tile t = ot * NT + nt' -> wave t % 4, slot t / 4
+    f32x16 acc2[4], acc3[2];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc2[q][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc3[q][r] = 0.f;
+    float db2 = 0.f, db3[2] = {0.f, 0.f};
+
+    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const int row_l = wave * 32 + c;               // row inside the block tile
+        const int g_raw = it * FB_ROWS + row_l;
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        // ---- 1. trunk recompute, a^T -> LDS ----
+        float a[NT][16];
+        {
+            float eb[1][16];
+            load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
+                acc = gemm_tile<1>(fr + d.fl.F1 + (size_t)nt * 1024, eb, acc, lane);
+#pragma unroll
+                for (int r = 0; r < 16; r++) a[nt][r] = gvalid ? fmaxf(acc[r], 0.f) : 0.f;
+                lds_store_tile_T(A_T, row_l, nt, h, a[nt]);
+            }
+        }
+        // ---- 2. upstream gradient of this head's output as MFMA B operand ----
+        float gy[OTMAX][16];
+#pragma unroll
+        for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
+        if (gvalid) {
+            if (k < 4) {
+                if (h == 0) {
+                    for (int j = 0; j < nk; j++) {
+                        float v = 0.f;
+                        if (gA) v += gA[(size_t)g * nk + j];
+                        if (gB) v += gB[(size_t)g * nk + j];
+                        gy[0][j] = v * hc;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int cidx = 0; cidx < 6; cidx++) {
+                    const int feat = (cidx >> 2) * 32 + 8 * (cidx & 3) + 4 * h;
+                    float4 v = make_float4(0, 0, 0, 0);
+                    if (feat < shw) {
+                        if (gA) { float4 t = *reinterpret_cast<const float4 *>(gA + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        if (gB) { float4 t = *reinterpret_cast<const float4 *>(gB + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                    }
+                    const int ot = cidx >> 2, kk0 = 4 * (cidx & 3);
+                    gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                }
+            }
+        }
+        // ---- 3. z tiles: relu(z)^T -> LDS, keep the sign mask ----
+        unsigned long long zmask = 0ull;
+#pragma unroll 1
+        for (int nt = 0; nt < NT; nt++) {
+            f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+            acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
+            float z[16];
+            unsigned m16 = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { z[r] = gvalid ? fmaxf(acc[r], 0.f) : 0.f; m16 |= (z[r] > 0.f) ? (1u << r) : 0u; }
+            zmask |= (unsigned long long)m16 << (16 * nt);
+            lds_store_tile_T(Z_T, row_l, nt, h, z);
+        }
+        __syncthreads();
+        // ---- 4. dW3_k += (hc g_out)^T relu(z) ; db3 += column sums of hc g_out ----
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int t = wave + 4 * q;
+            if (t < nout * NT && !(d.ablate & 1)) {
+                const int ot = t / NT, ntp = t % NT;
+                const int j = ot * 32 + c;
+                const bool jok = j < nk;
+                float bsum = 0.f;
+#pragma unroll 4
+                for (int kk = 0; kk < FB_ROWS / 2; kk++) {
+                    const int rl = 2 * kk + h, gr = it * FB_ROWS + rl;
+                    float av = 0.f;
+                    if (jok && gr < d.P) {
+                        if (gA) av += gA[(size_t)gr * nk + j];
+                        if (gB) av += gB[(size_t)gr * nk + j];
+                        av *= hc;
+                    }
+                    bsum += av;
+                    acc3[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Z_T[rl * FB_LD + ntp * 32 + c], acc3[q], 0, 0, 0);
+                }
+                if (ntp == 0) db3[q] += bsum + __shfl_xor(bsum, 32);
+            }
+        }
+        __syncthreads();
+        // ---- 5. g_z tiles: g_z^T -> LDS (over relu(z)^T), g_a_k += W2^T g_z ----
+        f32x16 ga[NT];
+#pragma unroll
+        for (int i2 = 0; i2 < NT; i2++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ga[i2][r] = 0.f;
+#pragma unroll 1
+        for (int nt = 0; nt < NT; nt++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            if (k < 4) {
+                const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX) * 16) * 64;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int ot = 0; ot < OTMAX; ot++) {
+                    const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX + ot) * 16) * 64;
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[ot][kk], acc, 0, 0, 0);
+                }
+            }
+            float gz[1][16];
+            const unsigned m16 = (unsigned)(zmask >> (16 * nt)) & 0xFFFFu;
+#pragma unroll
+            for (int r = 0; r < 16; r++) gz[0][r] = (m16 >> r) & 1u ? acc[r] : 0.f;
+            lds_store_tile_T(Z_T, row_l, nt, h, gz[0]);
+            if (!(d.ablate & 8)) {
+#pragma unroll
+                for (int i2 = 0; i2 < NT; i2++)
+                    ga[i2] = gemm_tile<1>(fr + d.fl.F2T + ((((size_t)k * NT + i2) * NT) + nt) * 1024, gz, ga[i2], lane);
+            }
+        }
+        if (gvalid) {
+#pragma unroll
+            for (int i2 = 0; i2 < NT; i2++) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = ga[i2][r];
+                store_tile_rows(GA, d.W, g, i2, h, v);
+            }
+        }
+        __syncthreads();
+        // ---- 6. dW2_k += g_z^T a ; db2 += column sums of g_z ----
+        if (w2_on && !(d.ablate & 2)) {
+#pragma unroll 4
+            for (int kk = 0; kk < FB_ROWS / 2; kk++) {
+                const int rl = 2 * kk + h;
+                const float a0 = Z_T[rl * FB_LD + w2_m0 * 32 + c];
+                const float b0 = A_T[rl * FB_LD + w2_n0 * 32 + c];
+                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc2[0], 0, 0, 0);
+                if (NT >= 2) {
+                    const float a1 = Z_T[rl * FB_LD + (w2_m0 + 1) * 32 + c];
+                    const float b1 = A_T[rl * FB_LD + (w2_n0 + 1) * 32 + c];
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc2[1], 0, 0, 0);
+                    acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc2[2], 0, 0, 0);
+                    acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc2[3], 0, 0, 0);
+                }
+            }
+        }
+        if (tid < d.W && !(d.ablate & 4)) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < FB_ROWS; r++) sum += Z_T[r * FB_LD + tid];
+            db2 += sum;
+        }
+        __syncthreads();
+    }
+    // ---- flush ----
+    if (w2_on) {
+        float *dW2 = gp + pl.W2[k];
+#pragma unroll
+        for (int q = 0; q < (NT >= 2 ? 4 : 1); q++) {
+            const int mt = w2_m0 + (q >> 1), ntp = w2_n0 + (q & 1);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(dW2 + (size_t)mi * d.W + ntp * 32 + c, acc2[q][r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int t = wave + 4 * q;
+        if (t < nout * NT) {
+            const int ot = t / NT, ntp = t % NT;
+            float *dW3 = gp + pl.W3[k];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (j < nk) atomicAdd(dW3 + (size_t)j * d.W + ntp * 32 + c, acc3[q][r]);
+            }
+            if (ntp == 0 && h == 0 && ot * 32 + c < nk) atomicAdd(gp + pl.b3[k] + ot * 32 + c, db3[q]);
+        }
+    }
+    if (tid < d.W) atomicAdd(gp + pl.b2[k] + tid, db2);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_bwd_trunk_kernel(DeformDev d, const float *GA0, const float *GA1, float *gp0, float *gp1, ParamLayout pl)
+{
+    extern __shared__ float fb_lds[];
+    float *GH_T = fb_lds;  // [128][132]  g_hid^T
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_iter = (d.P + FB_ROWS - 1) / FB_ROWS;
+    f32x16 acc1[2];  // dW1[:, TD:] tile mt = wave (NT <= 4), one per stage
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc1[q][r] = 0.f;
+    float db1[2] = {0.f, 0.f};
+    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const int row_l = wave * 32 + c;
+        const int g_raw = it * FB_ROWS + row_l;
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        float eb[1][16];
+        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+        f32x16 ge;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ge[r] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (!d.use_stage[s]) continue;
+            const float *fr = d.frag[s];
+            const float *GA = (s == 0 ? GA0 : GA1);
+            float gh[NT][16];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
+                acc = gemm_tile<1>(fr + d.fl.F1 + (size_t)nt * 1024, eb, acc, lane);
+                float sum[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum[r] = 0.f;
+                for (int k = 0; k < NHEAD; k++) {
+                    if (!d.enabled[k]) continue;
+                    const float4 *row = reinterpret_cast<const float4 *>(GA + ((size_t)k * d.P + g) * d.W + nt * 32 + 4 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const float4 v = row[2 * q]; sum[4 * q] += v.x; sum[4 * q + 1] += v.y; sum[4 * q + 2] += v.z; sum[4 * q + 3] += v.w; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) gh[nt][r] = (gvalid && acc[r] > 0.f) ? sum[r] : 0.f;
+                lds_store_tile_T(GH_T, row_l, nt, h, gh[nt]);
+            }
+            ge = gemm_tile<NT>(fr + d.fl.F1T, gh, ge, lane);
+            __syncthreads();
+            if (wave < NT) {
+#pragma unroll 4
+                for (int kk = 0; kk < FB_ROWS / 2; kk++) {
+                    const int rl = 2 * kk + h, gr = it * FB_ROWS + rl;
+                    const float bv = gr < d.P ? d.emb[(size_t)gr * d.E + c] : 0.f;
+                    if (s == 0) acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(GH_T[rl * FB_LD + wave * 32 + c], bv, acc1[0], 0, 0, 0);
+                    else        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(GH_T[rl * FB_LD + wave * 32 + c], bv, acc1[1], 0, 0, 0);
+                }
+            }
+            if (tid < d.W) {
+                float sum = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < FB_ROWS; r++) sum += GH_T[r * FB_LD + tid];
+                if (s == 0) db1[0] += sum; else db1[1] += sum;
+            }
+            __syncthreads();
+        }
+        if (gvalid) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = ge[r];
+            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (!d.use_stage[s]) continue;
+        float *gp = (s == 0 ? gp0 : gp1);
+        if (wave < NT) {
+            float *dW1 = gp + pl.W1 + d.TD;
+            const int ld = d.TD + d.E;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mi = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(dW1 + (size_t)mi * ld + c, s == 0 ? acc1[0][r] : acc1[1][r]);
+            }
+        }
+        if (tid < d.W) atomicAdd(gp + pl.b1 + tid, s == 0 ? db1[0] : db1[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward, weight-gradient part: dW[m][n] += sum_p G[p][m] * X[p][n], db[m] += sum_p G[p][m], split over p
 // ------------------------------------------------------------------------------------------------------------
 struct WgradJob {
@@ -941,64 +1282,91 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     for (int i = 0; i < 5; i++) { d.g[i] = gg[i]; d.gs[i] = gsub[i]; }
     for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.GZ[st] = w.GZ[st]; d.GHID[st] = w.GHID[st]; }
     d.g_emb = g_embedding;
+    d.ablate = getenv("ED3DGS_FB_ABLATE") ? atoi(getenv("ED3DGS_FB_ABLATE")) : 0;
     if (!cfg->use_stage[0] && !cfg->use_stage[1]) {
         if (!check_hip(hipMemsetAsync(g_embedding, 0, (size_t)cfg->P * cfg->E * sizeof(float), s), "memset g_emb")) return ED3DGS_ERR_HIP;
         return 0;
     }
-    const int nstrips = (cfg->P + 31) / 32;
-    const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
-    dispatch_nt(d.NT, [&](auto nt) {
-        hipLaunchKernelGGL((deform_dgrad_kernel<decltype(nt)::value>), dim3(blocks), dim3(256), 0, s, d);
-    });
-    if (!check_hip(hipGetLastError(), "deform dgrad")) return ED3DGS_ERR_HIP;
-
-    // weight gradients: jobs of at most 128 x 128 (one block tile), launched in batches of MAXJOBS
-    std::vector<WgradJob> jobs;
-    auto add_job = [&](const float *G, const float *G2, int ldg, int M, float gscale, const float *X, int ldx, int N,
-                       float *dW, int ldd, float *db) {
-        for (int m0 = 0; m0 < M; m0 += 128)
-            for (int n0 = 0; n0 < N; n0 += 128) {
-                WgradJob J;
-                J.G = G + m0; J.G2 = G2 ? G2 + m0 : nullptr; J.ldg = ldg; J.M = std::min(128, M - m0); J.gscale = gscale;
-                J.X = X + n0; J.ldx = ldx; J.N = std::min(128, N - n0);
-                J.dW = dW + (size_t)m0 * ldd + n0; J.ldd = ldd; J.db = (db && n0 == 0) ? db + m0 : nullptr;
-                jobs.push_back(J);
+    if (d.NT <= 4 && getenv("ED3DGS_DEFORM_FUSED_BWD")) {
+        // EXPERIMENTAL fused path (opt-in): weight gradients accumulated on chip, only g_a partials ([5][P][W] per
+        // stage, aliased onto the generic path's ZR region) round-trip HBM.  Parity-green, 3x less HBM traffic, but at
+        // one wave per SIMD (135 KB of LDS per block) it is MFMA-busy only 32 % of the time and currently slower
+        // (7.7 ms vs 4.9 ms at 200k Gaussians) than the dgrad + wgrad pair below.
+        const size_t lds1 = (size_t)2 * FB_ROWS * FB_LD * sizeof(float), lds2 = (size_t)FB_ROWS * FB_LD * sizeof(float);
+        const int n_iter = (cfg->P + FB_ROWS - 1) / FB_ROWS;
+        int nblk = 0;
+        for (int st = 0; st < 2; st++) for (int k = 0; k < NHEAD; k++) nblk += (cfg->use_stage[st] && d.enabled[k]);
+        const int G1 = std::max(1, std::min(n_iter, 256 / std::max(nblk, 1)));
+        const int G2 = std::max(1, std::min(n_iter, 512));
+        bool okl = true;
+        dispatch_nt(d.NT, [&](auto nt) {
+            constexpr int N = decltype(nt)::value;
+            if constexpr (N <= 4) {
+                okl = okl && check_hip(hipFuncSetAttribute((const void *)deform_bwd_head_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "set LDS size");
+                okl = okl && check_hip(hipFuncSetAttribute((const void *)deform_bwd_trunk_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), "set LDS size");
+                if (okl) {
+                    hipLaunchKernelGGL((deform_bwd_head_kernel<N>), dim3(G1, NHEAD, 2), dim3(256), lds1, s, d, w.ZR[0], w.ZR[1], gparams[0], gparams[1], pl);
+                    hipLaunchKernelGGL((deform_bwd_trunk_kernel<N>), dim3(G2), dim3(256), lds2, s, d, (const float *)w.ZR[0], (const float *)w.ZR[1], gparams[0], gparams[1], pl);
+                }
             }
-    };
-    const bool both = cfg->use_stage[0] && cfg->use_stage[1];
-    for (int st = 0; st < 2; st++) {
-        if (!cfg->use_stage[st]) continue;
-        const bool add_sub = (st == 0), add_out = (st == 1) || both || !cfg->use_stage[1];
-        const size_t PW = (size_t)cfg->P * cfg->W;
-        for (int k = 0; k < NHEAD; k++) {
-            if (!d.enabled[k]) continue;
-            const float *G = add_out ? gg[k] : nullptr, *G2 = add_sub ? gsub[k] : nullptr;
-            if (!G) { G = G2; G2 = nullptr; }
-            if (G)  // dW3 / db3 from the upstream gradient of the head's output
-                add_job(G, G2, d.nk[k], d.nk[k], d.hc[k], w.ZR[st] + k * PW, cfg->W, cfg->W, gparams[st] + pl.W3[k],
-                        cfg->W, gparams[st] + pl.b3[k]);
-            add_job(w.GZ[st] + k * PW, nullptr, cfg->W, cfg->W, 1.f, w.A[st], cfg->W, cfg->W, gparams[st] + pl.W2[k],
-                    cfg->W, gparams[st] + pl.b2[k]);  // dW2 / db2
-        }
-        add_job(w.GHID[st], nullptr, cfg->W, cfg->W, 1.f, embedding, cfg->E, cfg->E, gparams[st] + pl.W1 + cfg->TD,
-                cfg->TD + cfg->E, gparams[st] + pl.b1);  // dW1[:, TD:] and db1 (= g_hb)
-    }
-    const int nj_total = (int)jobs.size();
-    // one resident round of blocks (2 per CU at 64 KB of LDS each)
-    int ksplit = std::max(1, std::min((cfg->P + 255) / 256, (256 * 2) / std::max(nj_total, 1)));
-    int chunk = ((cfg->P + ksplit - 1) / ksplit + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
-    ksplit = (cfg->P + chunk - 1) / chunk;
-    const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
-    for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
-        WgradArgs wa;
-        std::memset(&wa, 0, sizeof wa);
-        wa.P = cfg->P; wa.ksplit = ksplit; wa.chunk = chunk;
-        wa.njobs = std::min(MAXJOBS, nj_total - j0);
-        for (int q = 0; q < wa.njobs; q++) wa.job[q] = jobs[j0 + q];
-        hipLaunchKernelGGL(deform_wgrad_kernel, dim3(wa.njobs, ksplit), dim3(256), wg_lds, s, wa);
-    }
-    if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
+        });
+        if (!okl || !check_hip(hipGetLastError(), "deform fused backward")) return ED3DGS_ERR_HIP;
+    } else {
+        const int nstrips = (cfg->P + 31) / 32;
+        const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
+        dispatch_nt(d.NT, [&](auto nt) {
+            hipLaunchKernelGGL((deform_dgrad_kernel<decltype(nt)::value>), dim3(blocks), dim3(256), 0, s, d);
+        });
+        if (!check_hip(hipGetLastError(), "deform dgrad")) return ED3DGS_ERR_HIP;
 
+        // weight gradients: jobs of at most 128 x 128 (one block tile), launched in batches of MAXJOBS
+        std::vector<WgradJob> jobs;
+        auto add_job = [&](const float *G, const float *G2, int ldg, int M, float gscale, const float *X, int ldx, int N,
+                           float *dW, int ldd, float *db) {
+            for (int m0 = 0; m0 < M; m0 += 128)
+                for (int n0 = 0; n0 < N; n0 += 128) {
+                    WgradJob J;
+                    J.G = G + m0; J.G2 = G2 ? G2 + m0 : nullptr; J.ldg = ldg; J.M = std::min(128, M - m0); J.gscale = gscale;
+                    J.X = X + n0; J.ldx = ldx; J.N = std::min(128, N - n0);
+                    J.dW = dW + (size_t)m0 * ldd + n0; J.ldd = ldd; J.db = (db && n0 == 0) ? db + m0 : nullptr;
+                    jobs.push_back(J);
+                }
+        };
+        const bool both = cfg->use_stage[0] && cfg->use_stage[1];
+        for (int st = 0; st < 2; st++) {
+            if (!cfg->use_stage[st]) continue;
+            const bool add_sub = (st == 0), add_out = (st == 1) || both || !cfg->use_stage[1];
+            const size_t PW = (size_t)cfg->P * cfg->W;
+            for (int k = 0; k < NHEAD; k++) {
+                if (!d.enabled[k]) continue;
+                const float *G = add_out ? gg[k] : nullptr, *G2 = add_sub ? gsub[k] : nullptr;
+                if (!G) { G = G2; G2 = nullptr; }
+                if (G)  // dW3 / db3 from the upstream gradient of the head's output
+                    add_job(G, G2, d.nk[k], d.nk[k], d.hc[k], w.ZR[st] + k * PW, cfg->W, cfg->W, gparams[st] + pl.W3[k],
+                            cfg->W, gparams[st] + pl.b3[k]);
+                add_job(w.GZ[st] + k * PW, nullptr, cfg->W, cfg->W, 1.f, w.A[st], cfg->W, cfg->W, gparams[st] + pl.W2[k],
+                        cfg->W, gparams[st] + pl.b2[k]);  // dW2 / db2
+            }
+            add_job(w.GHID[st], nullptr, cfg->W, cfg->W, 1.f, embedding, cfg->E, cfg->E, gparams[st] + pl.W1 + cfg->TD,
+                    cfg->TD + cfg->E, gparams[st] + pl.b1);  // dW1[:, TD:] and db1 (= g_hb)
+        }
+        const int nj_total = (int)jobs.size();
+        // one resident round of blocks (2 per CU at 64 KB of LDS each)
+        int ksplit = std::max(1, std::min((cfg->P + 255) / 256, (256 * 2) / std::max(nj_total, 1)));
+        int chunk = ((cfg->P + ksplit - 1) / ksplit + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+        ksplit = (cfg->P + chunk - 1) / chunk;
+        const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
+        for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
+            WgradArgs wa;
+            std::memset(&wa, 0, sizeof wa);
+            wa.P = cfg->P; wa.ksplit = ksplit; wa.chunk = chunk;
+            wa.njobs = std::min(MAXJOBS, nj_total - j0);
+            for (int q = 0; q < wa.njobs; q++) wa.job[q] = jobs[j0 + q];
+            hipLaunchKernelGGL(deform_wgrad_kernel, dim3(wa.njobs, ksplit), dim3(256), wg_lds, s, wa);
+        }
+        if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
+
+    }
     FrameBwdArgs fb;
     fb.W = cfg->W; fb.E = cfg->E; fb.TD = cfg->TD; fb.max_emb = cfg->max_embeddings; fb.num_offsets = cfg->num_offsets;
     fb.cam_no = cfg->cam_no; fb.W1_off = pl.W1; fb.b1_off = pl.b1; fb.fs = w.fs; fb.offsets = offsets;
