@@ -57,7 +57,8 @@ __host__ __device__ inline ParamLayout param_layout(int W, int TD, int E, int n_
 
 // fragment workspace of one stage (float offsets)
 struct FragLayout {
-    size_t F1, F2, F3, B2, B3, HB, F1T, F2T, F3T, total;
+    size_t F1, F2, F3, B2, B3, HB, F1T, F2T, F3T, CH, total;  // CH: weight chunks in consumption order (pipelined kernels)
+    int ch_floats, n_chunks;
 };
 __host__ __device__ inline FragLayout frag_layout(int W, int E, bool bwd)
 {
@@ -72,6 +73,13 @@ __host__ __device__ inline FragLayout frag_layout(int W, int E, bool bwd)
     L.F1T = o; if (bwd) o += (size_t)W * E;
     L.F2T = o; if (bwd) o += (size_t)NHEAD * W * W;
     L.F3T = o; if (bwd) o += (size_t)NHEAD * OTMAX * 32 * W;
+    // chunked copy for the LDS-pipelined kernels (E == 32 only): forward chunk (k, nt) = [F2[k][nt] | F3[k][:][nt]],
+    // backward chunk = [F2[k][nt] | F3T[k][nt][:] | F2T[k][:][nt]]; chunk 0 = F1, last backward chunk = F1T
+    const int NT = W / 32;
+    L.ch_floats = (bwd ? 2 * NT + OTMAX : NT + OTMAX) * 1024;
+    L.n_chunks = 1 + NHEAD * NT + (bwd ? 1 : 0);
+    o = (o + 63) & ~(size_t)63;
+    L.CH = o; if (E == 32 && NT <= 4) o += (size_t)L.n_chunks * L.ch_floats;
     L.total = (o + 63) & ~(size_t)63;
     return L;
 }
@@ -271,6 +279,43 @@ __global__ void __launch_bounds__(256) deform_frag_kernel(FragArgs a)
         int k = (int)(i / (OTMAX * 32)), o = (int)(i % (OTMAX * 32));
         f[a.fl.B3 + i] = o < head_nk(k, a.n_sh) ? p[a.pl.b3[k] + o] : 0.f;
     }
+}
+
+// chunk builder for the LDS-pipelined kernels: one thread per chunk element (see frag_layout)
+__global__ void __launch_bounds__(256) deform_chunk_kernel(FragArgs a)
+{
+    const int s = blockIdx.y;
+    if (!a.use_stage[s]) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
+    const int CHF = a.fl.ch_floats;
+    if (idx >= (size_t)a.fl.n_chunks * CHF) return;
+    const int cidx = (int)(idx / CHF), o = (int)(idx % CHF);
+    const int lane = o & 63, kk = (o >> 6) & 15, t = o >> 10;  // t = 1024-float tile index inside the chunk
+    const int fs = fslot(kk, lane >> 5), cl = lane & 31;
+    const float *p = a.params[s];
+    float v = 0.f;
+    if (cidx == 0) {                       // F1[nt = t]
+        if (t < NT) v = p[a.pl.W1 + (size_t)(t * 32 + cl) * ld1 + a.TD + fs];
+    } else if (a.bwd && cidx == a.fl.n_chunks - 1) {  // F1T[kt = t]: A[i = e][k-slot = hidden feature]
+        if (t < NT) v = p[a.pl.W1 + (size_t)(t * 32 + fs) * ld1 + a.TD + cl];
+    } else {
+        const int k = (cidx - 1) / NT, nt = (cidx - 1) % NT;
+        const int nk = head_nk(k, a.n_sh);
+        if (t < NT) {                      // F2[k][nt][kt = t]
+            v = p[a.pl.W2[k] + (size_t)(nt * 32 + cl) * W + t * 32 + fs];
+        } else if (!a.bwd) {               // F3[k][ot][kt = nt]
+            const int ot = t - NT, row = ot * 32 + cl;
+            if (row < nk) v = p[a.pl.W3[k] + (size_t)row * W + nt * 32 + fs];
+        } else if (t < NT + OTMAX) {       // F3T[k][it = nt][ot]: A[i = hidden feature][k-slot = output]
+            const int ot = t - NT, row = ot * 32 + fs;
+            if (row < nk) v = p[a.pl.W3[k] + (size_t)row * W + nt * 32 + cl];
+        } else {                           // F2T[k][it][ot = nt]: A[i = in feature][k-slot = out feature of tile nt]
+            const int itile = t - NT - OTMAX;
+            v = p[a.pl.W2[k] + (size_t)(nt * 32 + fs) * W + itile * 32 + cl];
+        }
+    }
+    a.frag[s][a.fl.CH + idx] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -544,6 +589,324 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh[nt]);
             }
             ge = gemm_tile<NT>(fr + d.fl.F1T, gh, ge, lane);
+        }
+        if (gvalid) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = ge[r];
+            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS-pipelined variants (W <= 128, E == 32): the four waves of a block walk their four strips in lockstep and share
+// the weight fragments through LDS.  Weights are consumed as a fixed sequence of equally sized chunks (frag_layout:
+// trunk, then (head, out-tile) pairs, then the transposed trunk for the backward); chunk n+1 sits in registers and
+// chunk n+2's global loads are in flight while chunk n is multiplied out of LDS (double buffer, one barrier per chunk).
+// Compared with every wave fetching every fragment itself: 4x less L2 traffic and LDS instead of L2 latency in front
+// of each MFMA.
+// ------------------------------------------------------------------------------------------------------------
+template <int KT>
+__device__ __forceinline__ f32x16 gemm_tile_lds(const float *wl, const float (&x)[KT][16], f32x16 acc, int lane)
+{
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(kt * 16 + kk) * 64 + lane], x[kt][kk], acc, 0, 0, 0);
+    return acc;
+}
+
+// order in which the kernels consume chunks: per block iteration, per used stage: chunk 0, (k, nt) for enabled heads,
+// [last chunk if BWD]
+template <int NT, bool BWD>
+struct ChunkSeq {
+    int s, k, nt;  // k = -1: trunk chunk, k = NHEAD: transposed trunk chunk (BWD)
+    __device__ __forceinline__ void init(const DeformDev &d) { s = d.use_stage[0] ? 0 : 1; k = -1; nt = 0; }
+    __device__ __forceinline__ const float *next(const DeformDev &d)
+    {
+        const int n_chunks = 1 + NHEAD * NT + (BWD ? 1 : 0);
+        const int ch = (BWD ? 2 * NT + OTMAX : NT + OTMAX) * 1024;
+        const int cidx = (k < 0) ? 0 : (k >= NHEAD ? n_chunks - 1 : 1 + k * NT + nt);
+        const float *p = d.frag[s] + d.fl.CH + (size_t)cidx * ch;
+        // advance
+        if (k >= 0 && k < NHEAD && nt + 1 < NT) { nt++; return p; }
+        nt = 0;
+        int kn = (k >= NHEAD) ? NHEAD + 1 : k + 1;
+        while (kn < NHEAD && !d.enabled[kn]) kn++;
+        if (kn < NHEAD) { k = kn; return p; }
+        if (BWD && kn == NHEAD) { k = NHEAD; return p; }
+        k = -1;  // next stage (or wrap to the first used stage = next block iteration)
+        s = (s == 0 && d.use_stage[1]) ? 1 : (d.use_stage[0] ? 0 : 1);
+        return p;
+    }
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int N>
+__device__ __forceinline__ void stage_load(f32x4 (&st)[N], const f32x4 *__restrict__ src, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) st[i] = src[i * 256 + tid];
+}
+template <int N>
+__device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restrict__ dst, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) dst[i * 256 + tid] = st[i];
+}
+
+// The staging registers must stay scalar-replaceable, so the pipe is plain macros over kernel-local variables
+// (closures capturing the array end up in scratch memory).
+#define ED3_CHUNK_PIPE(NT_, BWD_)                                                                  \
+    constexpr int PIPE_CHF = ((BWD_) ? 2 * (NT_) + OTMAX : (NT_) + OTMAX) * 1024;                 \
+    constexpr int PIPE_NF4 = PIPE_CHF / 4 / 256;                                                  \
+    f32x4 pipe_st[PIPE_NF4];                                                                      \
+    ChunkSeq<NT_, BWD_> pipe_seq;                                                                 \
+    int pipe_n = 0, pipe_total = 0;
+#define PIPE_LOAD() stage_load<PIPE_NF4>(pipe_st, reinterpret_cast<const f32x4 *>(pipe_seq.next(d)), tid)
+#define PIPE_COMMIT(buf_) stage_store<PIPE_NF4>(pipe_st, reinterpret_cast<f32x4 *>(wl + (buf_) * PIPE_CHF), tid)
+#define PIPE_CUR() (wl + (pipe_n & 1) * PIPE_CHF)
+#define PIPE_START(total_)                                                                         \
+    do {                                                                                           \
+        pipe_seq.init(d); pipe_n = 0; pipe_total = (total_);                                       \
+        if (pipe_total > 0) { PIPE_LOAD(); PIPE_COMMIT(0); }                                       \
+        __syncthreads();                                                                           \
+        if (pipe_total > 1) PIPE_LOAD();                                                           \
+    } while (0)
+/* call after the last MFMA that reads chunk n */
+#define PIPE_ADVANCE()                                                                             \
+    do {                                                                                           \
+        if (pipe_n + 1 < pipe_total) PIPE_COMMIT((pipe_n + 1) & 1);                                \
+        __syncthreads();                                                                           \
+        if (pipe_n + 2 < pipe_total) PIPE_LOAD();                                                  \
+        pipe_n++;                                                                                  \
+    } while (0)
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_forward_pipe_kernel(DeformDev d)
+{
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_bi = (d.P + 127) / 128;
+    const int shw = 3 * d.n_sh;
+    int n_en = 0;
+    for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k] ? 1 : 0;
+    const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (1 + n_en * NT);
+    const int my_iters = (n_bi > (int)blockIdx.x) ? (n_bi - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    ED3_CHUNK_PIPE(NT, false)
+    PIPE_START(my_iters * per_iter);
+    for (int bi = blockIdx.x; bi < n_bi; bi += gridDim.x) {
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        float cx[3], cs[3], cr[4], co, csh[24];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { cx[i] = d.xyz[(size_t)g * 3 + i]; cs[i] = d.scales[(size_t)g * 3 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) cr[i] = d.rot[(size_t)g * 4 + i];
+        co = d.opacity[g];
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+            const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+            csh[4 * cc] = v.x; csh[4 * cc + 1] = v.y; csh[4 * cc + 2] = v.z; csh[4 * cc + 3] = v.w;
+        }
+        float eb[1][16];
+        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (d.use_stage[s]) {
+                const float *fr = d.frag[s];
+                float a[NT][16];
+                {
+                    const float *wb = PIPE_CUR();
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
+                        acc = gemm_tile_lds<1>(wb + nt * 1024, eb, acc, lane);
+#pragma unroll
+                        for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r], 0.f);
+                    }
+                    PIPE_ADVANCE();
+                }
+                for (int k = 0; k < NHEAD; k++) {
+                    if (!d.enabled[k]) continue;
+                    f32x16 y[OTMAX];
+#pragma unroll
+                    for (int ot = 0; ot < OTMAX; ot++) y[ot] = bias_acc(fr + d.fl.B3 + (size_t)k * OTMAX * 32, ot, h);
+                    const int nout = d.ot[k];
+#pragma unroll 1
+                    for (int nt = 0; nt < NT; nt++) {
+                        const float *wb = PIPE_CUR();
+                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                        acc = gemm_tile_lds<NT>(wb, a, acc, lane);
+                        float z[1][16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                        y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
+                        if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
+                        PIPE_ADVANCE();
+                    }
+                    const float hc = d.hc[k];
+                    if (k == 0) { if (h == 0) { cx[0] += y[0][0] * hc; cx[1] += y[0][1] * hc; cx[2] += y[0][2] * hc; } }
+                    else if (k == 1) { if (h == 0) { cs[0] += y[0][0] * hc; cs[1] += y[0][1] * hc; cs[2] += y[0][2] * hc; } }
+                    else if (k == 2) { if (h == 0) { cr[0] += y[0][0] * hc; cr[1] += y[0][1] * hc; cr[2] += y[0][2] * hc; cr[3] += y[0][3] * hc; } }
+                    else if (k == 3) { if (h == 0) co += y[0][0] * hc; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) csh[r] += y[0][r] * hc;
+#pragma unroll
+                        for (int r = 0; r < 8; r++) csh[16 + r] += y[1][r] * hc;
+                    }
+                }
+            }
+            float *const *dst = (s == 0) ? d.sub : d.out;
+            if (gvalid && dst[0]) {
+                if (h == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { dst[0][(size_t)g * 3 + i] = cx[i]; dst[1][(size_t)g * 3 + i] = cs[i]; }
+                    *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    dst[3][g] = co;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) {
+                    const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                    if (feat < shw)
+                        *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
+                            make_float4(csh[4 * cc], csh[4 * cc + 1], csh[4 * cc + 2], csh[4 * cc + 3]);
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_dgrad_pipe_kernel(DeformDev d)
+{
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_bi = (d.P + 127) / 128;
+    const int shw = 3 * d.n_sh;
+    const bool both = d.use_stage[0] && d.use_stage[1];
+    int n_en = 0;
+    for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k] ? 1 : 0;
+    const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (2 + n_en * NT);
+    const int my_iters = (n_bi > (int)blockIdx.x) ? (n_bi - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    ED3_CHUNK_PIPE(NT, true)
+    PIPE_START(my_iters * per_iter);
+    for (int bi = blockIdx.x; bi < n_bi; bi += gridDim.x) {
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        float eb[1][16];
+        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+        f32x16 ge;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ge[r] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (!d.use_stage[s]) continue;
+            const float *fr = d.frag[s];
+            const bool add_sub = (s == 0);
+            const bool add_out = (s == 1) || both || !d.use_stage[1];
+            float a[NT][16];
+            {
+                const float *wb = PIPE_CUR();
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
+                    acc = gemm_tile_lds<1>(wb + nt * 1024, eb, acc, lane);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r], 0.f);
+                    if (gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
+                }
+                PIPE_ADVANCE();
+            }
+            f32x16 ga[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
+            for (int k = 0; k < NHEAD; k++) {
+                if (!d.enabled[k]) continue;
+                const float hc = d.hc[k];
+                const int nk = d.nk[k];
+                float gy[OTMAX][16];
+#pragma unroll
+                for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
+                if (k < 4) {
+                    if (h == 0) {
+                        for (int j = 0; j < nk; j++) {
+                            float v = 0.f;
+                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
+                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
+                            gy[0][j] = v * hc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) {
+                        const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                        float4 v = make_float4(0, 0, 0, 0);
+                        if (feat < shw) {
+                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        }
+                        const int ot = cc >> 2, kk0 = 4 * (cc & 3);
+                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                    }
+                }
+#pragma unroll 1
+                for (int nt = 0; nt < NT; nt++) {
+                    const float *wb = PIPE_CUR();
+                    float z[1][16];
+                    {
+                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                        acc = gemm_tile_lds<NT>(wb, a, acc, lane);
+#pragma unroll
+                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                    }
+                    if (gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    const float *f3t = wb + NT * 1024;
+                    if (k < 4) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[(ot * 16 + kk) * 64 + lane], gy[ot][kk], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[0][r] = z[0][r] > 0.f ? acc[r] : 0.f;
+                    if (gvalid) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+#pragma unroll
+                    for (int i2 = 0; i2 < NT; i2++)
+                        ga[i2] = gemm_tile_lds<1>(wb + (NT + OTMAX + i2) * 1024, z, ga[i2], lane);
+                    PIPE_ADVANCE();
+                }
+            }
+            float gh[NT][16];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) gh[nt][r] = a[nt][r] > 0.f ? ga[nt][r] : 0.f;
+                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh[nt]);
+            }
+            ge = gemm_tile_lds<NT>(PIPE_CUR(), gh, ge, lane);
+            PIPE_ADVANCE();
         }
         if (gvalid) {
             float v[16];
@@ -1184,6 +1547,10 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     const size_t nelem = (size_t)c->W * c->E + (size_t)NHEAD * c->W * c->W + (size_t)NHEAD * OTMAX * 32 * c->W +
                          (size_t)NHEAD * c->W + (size_t)NHEAD * OTMAX * 32;
     hipLaunchKernelGGL(deform_frag_kernel, dim3((unsigned)((nelem + 255) / 256), 2), dim3(256), 0, s, fa);
+    if (c->E == 32 && c->W <= 128) {
+        const size_t nch = (size_t)fl.n_chunks * fl.ch_floats;
+        hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+    }
     hipLaunchKernelGGL(deform_frame_kernel, dim3(2), dim3(256), 0, s, fr);
     return check_hip(hipGetLastError(), "deform prep");
 }
@@ -1242,8 +1609,17 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     for (int i = 0; i < 5; i++) { d.out[i] = outs[i]; d.sub[i] = have_sub ? subs[i] : nullptr; }
     const int nstrips = (cfg->P + 31) / 32;
     const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
+    const bool piped = d.NT <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
     dispatch_nt(d.NT, [&](auto nt) {
-        hipLaunchKernelGGL((deform_forward_kernel<decltype(nt)::value>), dim3(blocks), dim3(256), 0, s, d);
+        constexpr int N = decltype(nt)::value;
+        if constexpr (N <= 4) {
+            if (piped) {  // weights shared through LDS by the block's four waves
+                const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
+                hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 256)), dim3(256), lds, s, d);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((deform_forward_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
     });
     if (!check_hip(hipGetLastError(), "deform forward")) return ED3DGS_ERR_HIP;
     return 0;
@@ -1314,9 +1690,21 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     } else {
         const int nstrips = (cfg->P + 31) / 32;
         const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
+        const bool piped = d.NT <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+        bool okp = true;
         dispatch_nt(d.NT, [&](auto nt) {
-            hipLaunchKernelGGL((deform_dgrad_kernel<decltype(nt)::value>), dim3(blocks), dim3(256), 0, s, d);
+            constexpr int N = decltype(nt)::value;
+            if constexpr (N <= 4) {
+                if (piped) {
+                    const size_t lds = (size_t)2 * (2 * N + OTMAX) * 1024 * sizeof(float);
+                    okp = check_hip(hipFuncSetAttribute((const void *)deform_dgrad_pipe_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size");
+                    if (okp) hipLaunchKernelGGL((deform_dgrad_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 256)), dim3(256), lds, s, d);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((deform_dgrad_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
         });
+        if (!okp) return ED3DGS_ERR_HIP;
         if (!check_hip(hipGetLastError(), "deform dgrad")) return ED3DGS_ERR_HIP;
 
         // weight gradients: jobs of at most 128 x 128 (one block tile), launched in batches of MAXJOBS
