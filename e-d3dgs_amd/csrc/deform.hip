@@ -1431,47 +1431,58 @@ struct FrameBwdArgs {
     const float *fs, *offsets;
     float *g_table, *g_offsets;
 };
+// grid = (ceil(TD / 64), 2 stages); thread (jj, og) owns column j = 64*blockIdx.x + jj and rows o = og (mod 4)
 __global__ void __launch_bounds__(256) deform_frame_bwd_kernel(FrameBwdArgs a)
 {
-    __shared__ float s_gt[32];
+    const int s = blockIdx.y;
+    if (!a.use_stage[s]) return;
+    __shared__ float s_gh[4][64];
+    __shared__ float s_gt[4];
     const int TD = a.TD, ld = TD + a.E;
-    float gt_local = 0.f;
-    for (int s = 0; s < 2; s++) {
-        if (!a.use_stage[s]) continue;
-        const float *fs = a.fs + (size_t)s * FS_STRIDE;
-        const float *W1 = a.params[s] + a.W1_off;
-        float *dW1 = a.gparams[s] + a.W1_off;
-        const float *ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
-        int rows[4]; float coefs[4];
-        for (int q = 0; q < 4; q++) { rows[q] = __float_as_int(fs[2 * TD + q]); coefs[q] = fs[2 * TD + 4 + q]; }
-        for (int j = threadIdx.x; j < TD; j += blockDim.x) {
-            const float hj = fs[j];
-            float gh = 0.f;
-            for (int o = 0; o < a.W; o++) {
-                const float gb = ghb[o];
-                dW1[(size_t)o * ld + j] = gb * hj;
-                gh += W1[(size_t)o * ld + j] * gb;
-            }
-            for (int q = 0; q < 4; q++) atomicAdd(a.g_table + (size_t)rows[q] * TD + j, coefs[q] * gh);
-            gt_local += gh * fs[TD + j];
+    const int jj = threadIdx.x & 63, og = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
+    const float *fs = a.fs + (size_t)s * FS_STRIDE;
+    const float *W1 = a.params[s] + a.W1_off;
+    float *dW1 = a.gparams[s] + a.W1_off;
+    const float *ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
+    float gh = 0.f;
+    if (j < TD) {
+        const float hj = fs[j];
+        for (int o = og; o < a.W; o += 4) {
+            const float gb = ghb[o];
+            dW1[(size_t)o * ld + j] = gb * hj;
+            gh += W1[(size_t)o * ld + j] * gb;
         }
     }
-    // block reduction of dL/dt
-    for (int off = 32; off >= 1; off >>= 1) gt_local += __shfl_xor(gt_local, off);
-    if ((threadIdx.x & 63) == 0) s_gt[threadIdx.x >> 6] = gt_local;
+    s_gh[og][jj] = gh;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float gt = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) gt += s_gt[w];
+    float gt = 0.f;
+    if (og == 0 && j < TD) {
+        gh = s_gh[0][jj] + s_gh[1][jj] + s_gh[2][jj] + s_gh[3][jj];
+        for (int q = 0; q < 4; q++) {
+            const int row = __float_as_int(fs[2 * TD + q]);
+            atomicAdd(a.g_table + (size_t)row * TD + j, fs[2 * TD + 4 + q] * gh);
+        }
+        gt = gh * fs[TD + j];
+    }
+    for (int off = 32; off >= 1; off >>= 1) gt += __shfl_xor(gt, off);
+    if (og == 0) {  // wave 0: every lane holds the block's dL/dt partial
         if (a.cam_no >= 0) {
-            a.g_offsets[a.cam_no] = gt;
-        } else {
-            int cnt = 0;
-            for (int i = 0; i < a.num_offsets; i++) cnt += (a.offsets[i] != 0.f);
-            for (int i = 0; i < a.num_offsets; i++)
-                if (a.offsets[i] != 0.f) a.g_offsets[i] = gt / (float)cnt;
+            if (jj == 0) atomicAdd(a.g_offsets + a.cam_no, gt);
+        } else {  // mean over the non-zero offsets: each of them receives gt / count
+            for (int base = 0; base < a.num_offsets; base += 64) {
+                const int i = base + jj;
+                const bool nz = i < a.num_offsets && a.offsets[i] != 0.f;
+                int cnt = 0;
+                for (int b2 = 0; b2 < a.num_offsets; b2 += 64) {
+                    const int i2 = b2 + jj;
+                    cnt += __popcll(__ballot(i2 < a.num_offsets && a.offsets[i2] != 0.f));
+                }
+                if (nz) atomicAdd(a.g_offsets + i, gt / (float)cnt);
+            }
         }
     }
+    (void)s_gt;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1760,7 +1771,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     fb.cam_no = cfg->cam_no; fb.W1_off = pl.W1; fb.b1_off = pl.b1; fb.fs = w.fs; fb.offsets = offsets;
     fb.g_table = g_table; fb.g_offsets = g_offsets;
     for (int st = 0; st < 2; st++) { fb.use_stage[st] = cfg->use_stage[st]; fb.params[st] = params[st]; fb.gparams[st] = gparams[st]; }
-    hipLaunchKernelGGL(deform_frame_bwd_kernel, dim3(1), dim3(256), 0, s, fb);
+    hipLaunchKernelGGL(deform_frame_bwd_kernel, dim3((cfg->TD + 63) / 64, 2), dim3(256), 0, s, fb);
     if (!check_hip(hipGetLastError(), "deform frame backward")) return ED3DGS_ERR_HIP;
     return 0;
 }
