@@ -1266,8 +1266,8 @@ struct WgradJob {
 };
 constexpr int MAXJOBS = 24;
 struct WgradArgs {
-    int P, njobs, ksplit, chunk;
-    int tile_begin[MAXJOBS + 1];  // prefix sum of (m-tiles * n-tiles) per job
+    int P, njobs;
+    int blk_begin[MAXJOBS + 1];   // prefix sum of the number of Gaussian-range splits per job (work-proportional)
     WgradJob job[MAXJOBS];
 };
 
@@ -1280,12 +1280,16 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
     extern __shared__ float wg_lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile ownership branches stay scalar
-    const WgradJob &J = a.job[blockIdx.x];
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    const WgradJob &J = a.job[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
     const int Mp = (J.M + 31) & ~31, Np = (J.N + 31) & ~31;   // padded extents (LDS row strides)
     const int mt_n = Mp / 32, nt_n = Np / 32, ntiles = mt_n * nt_n;
     // two LDS buffers, addressed by offset into the one shared array (keeps the accesses in the LDS address space)
     const int buf_floats = WG_ROWS * (Mp + Np), x_off = WG_ROWS * Mp;
-    const int p0 = blockIdx.y * a.chunk, p1 = min(a.P, p0 + a.chunk);
+    const int chunk = ((a.P + nsplit - 1) / nsplit + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    const int p0 = split * chunk, p1 = min(a.P, p0 + chunk);
     if (p0 >= p1) return;
     const int nslab = (p1 - p0 + WG_ROWS - 1) / WG_ROWS;
 
@@ -1334,12 +1338,12 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
         const int r0 = p0 + slab * WG_ROWS;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if (gvec) {
+            if (gvec && g_r[i] < WG_ROWS) {
                 const size_t o = (size_t)min(r0 + g_r[i], p1 - 1) * J.ldg + min(g_c[i], J.M - 4);
                 gv[i] = *reinterpret_cast<const float4 *>(J.G + o);
                 if (has_g2) g2v[i] = *reinterpret_cast<const float4 *>(J.G2 + o);
             }
-            if (xvec) xv[i] = *reinterpret_cast<const float4 *>(J.X + (size_t)min(r0 + x_r[i], p1 - 1) * J.ldx + min(x_c[i], J.N - 4));
+            if (xvec && x_r[i] < WG_ROWS) xv[i] = *reinterpret_cast<const float4 *>(J.X + (size_t)min(r0 + x_r[i], p1 - 1) * J.ldx + min(x_c[i], J.N - 4));
         }
     };
     auto store_lds = [&](int slab, int buf) {
@@ -1750,20 +1754,34 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                     cfg->TD + cfg->E, gparams[st] + pl.b1);  // dW1[:, TD:] and db1 (= g_hb)
         }
         const int nj_total = (int)jobs.size();
-        // one resident round of blocks (2 per CU at 64 KB of LDS each)
-        int ksplit = std::max(1, std::min((cfg->P + 255) / 256, (256 * 2) / std::max(nj_total, 1)));
-        int chunk = ((cfg->P + ksplit - 1) / ksplit + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
-        ksplit = (cfg->P + chunk - 1) / chunk;
-        const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
-        for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
-            WgradArgs wa;
-            std::memset(&wa, 0, sizeof wa);
-            wa.P = cfg->P; wa.ksplit = ksplit; wa.chunk = chunk;
-            wa.njobs = std::min(MAXJOBS, nj_total - j0);
-            for (int q = 0; q < wa.njobs; q++) wa.job[q] = jobs[j0 + q];
-            hipLaunchKernelGGL(deform_wgrad_kernel, dim3(wa.njobs, ksplit), dim3(256), wg_lds, s, wa);
+    // Gaussian-range splits per job proportional to its MFMA work (tile rounds of 4 waves), so that all blocks of the
+    // one resident round (2 blocks per CU at 64 KB of LDS) finish together
+    std::vector<int> cost(nj_total);
+    int cost_sum = 0;
+    for (int q = 0; q < nj_total; q++) {
+        const int tiles = ((jobs[q].M + 31) / 32) * ((jobs[q].N + 31) / 32);
+        cost[q] = (tiles + 3) / 4;
+        cost_sum += cost[q];
+    }
+    const int max_split = std::max(1, (cfg->P + 4 * WG_ROWS - 1) / (4 * WG_ROWS));
+    const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
+    for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
+        WgradArgs wa;
+        std::memset(&wa, 0, sizeof wa);
+        wa.P = cfg->P;
+        wa.njobs = std::min(MAXJOBS, nj_total - j0);
+        int nblk = 0;
+        for (int q = 0; q < wa.njobs; q++) {
+            wa.job[q] = jobs[j0 + q];
+            wa.blk_begin[q] = nblk;
+            // equal splits: every block streams the same number of Gaussians.  (Work-proportional splits were tried and
+            // lost 2x: a block's slab pipeline is latency-bound, so the narrow jobs became the long pole.)
+            nblk += std::max(1, std::min(max_split, 512 / std::max(nj_total, 1)));
         }
-        if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
+        wa.blk_begin[wa.njobs] = nblk;
+        hipLaunchKernelGGL(deform_wgrad_kernel, dim3(nblk), dim3(256), wg_lds, s, wa);
+    }
+    if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
 
     }
     FrameBwdArgs fb;
