@@ -47,6 +47,7 @@ class SynthGaussianModel:
         with torch.no_grad():
             self._deformation.weight.mul_(table_scale)  # make the synthetic deformation visible
         self._deformation = self._deformation.to(device)
+        self.fused_filter3D = True  # apply_scaling_n_opacity_with_3D_filter below is the reference formula -> fusable
         self.scaling_activation = torch.exp
         self.opacity_activation = torch.sigmoid
         self.rotation_activation = torch.nn.functional.normalize

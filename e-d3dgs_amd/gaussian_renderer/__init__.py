@@ -13,6 +13,14 @@ import math
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ed3dgs_amd.activations import fused_activations
+
+
+def _standard_activations(pc):
+    """True when the model's activation callables are the ones the reference installs
+    (scene/gaussian_model.py:37-45): only then may the fused HIP activation kernel stand in for them."""
+    return (getattr(pc, "scaling_activation", None) is torch.exp and getattr(pc, "opacity_activation", None) is torch.sigmoid
+            and getattr(pc, "rotation_activation", None) is torch.nn.functional.normalize)
 
 
 def _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord, require_depth):
@@ -64,12 +72,17 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
         means3D, scales, rotations, opacity, float(viewpoint_camera.time), cam_no, pc, None, shs, iter=iter,
         num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f)
 
-    rotations_final = pc.rotation_activation(rotations_final)
-    if disable_filter3D:
-        scales_final = pc.scaling_activation(scales_final)
-        opacity = pc.opacity_activation(opacity_final)
+    if scales_final is not None and _standard_activations(pc) and (disable_filter3D or getattr(pc, "fused_filter3D", False)):
+        # one fused launch per direction (csrc/activations.hip) instead of normalize / exp / sigmoid (/ 3D filter)
+        scales_final, rotations_final, opacity = fused_activations(
+            scales_final, rotations_final, opacity_final, None if disable_filter3D else pc.filter_3D)
     else:
-        scales_final, opacity = pc.apply_scaling_n_opacity_with_3D_filter(opacity=opacity_final, scales=scales_final)
+        rotations_final = pc.rotation_activation(rotations_final)
+        if disable_filter3D:
+            scales_final = pc.scaling_activation(scales_final)
+            opacity = pc.opacity_activation(opacity_final)
+        else:
+            scales_final, opacity = pc.apply_scaling_n_opacity_with_3D_filter(opacity=opacity_final, scales=scales_final)
 
     colors_precomp = None
     if override_color is None:

@@ -126,6 +126,17 @@ typedef struct ed3dgs_state_view {
 int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geometry_buffer,
                           const char *binning_buffer, const char *image_buffer, ed3dgs_state_view *out);
 
+/* Activations between the deformation network and the rasterizer (gaussian_renderer/__init__.py:77-83;
+ * scene/gaussian_model.py:37-45 and, with filter_3D != NULL, :594-603): rot = normalize(rot_raw), scales = exp(s) or
+ * sqrt(exp(s)^2 + f^2), opacity = sigmoid(o) [* sqrt(prod exp(s)^2 / prod(exp(s)^2 + f^2))].  Inputs/outputs [P,3],
+ * [P,4], [P]; filter_3D [P] or NULL.  Backward: g_* may be NULL (= zero); every output element is written. */
+int ed3dgs_activations_forward(int P, const float *scales_log, const float *rot_raw, const float *opacity_logit,
+                               const float *filter_3D, float *scales, float *rot, float *opacity, void *stream);
+int ed3dgs_activations_backward(int P, const float *scales_log, const float *rot_raw, const float *opacity_logit,
+                                const float *filter_3D, const float *g_scales, const float *g_rot,
+                                const float *g_opacity, float *g_scales_log, float *g_rot_raw, float *g_opacity_logit,
+                                void *stream);
+
 /* Measurement aid (bench.py): while enabled, the tile forward (K6) and tile backward (K7) launches are bracketed by
  * hipEvents on the stream they are launched on; ed3dgs_profile_end synchronises those events and returns the summed
  * kernel durations in milliseconds and the launch counts.  Not part of the data path. */

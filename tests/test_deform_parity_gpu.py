@@ -148,3 +148,32 @@ def test_against_torch_restatement(P, W):
     print("P", P, "W", W, "max err", max(errs.values()), "worst", max(errs, key=errs.get))
     for k, v in errs.items():
         assert v <= TOL, (k, v)
+
+
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_fused_activations_match_torch(with_filter):
+    """a7 (scene/gaussian_model.py:37-45, 594-603): the fused HIP activation kernel against the torch ops the
+    reference uses for them (values and gradients), fp32, tolerance 1e-5 relative."""
+    _need_gpu()
+    from ed3dgs_amd.activations import fused_activations
+    g = torch.Generator().manual_seed(3)
+    P = 5003
+    s = (torch.randn(P, 3, generator=g) * 0.5 - 3).cuda().requires_grad_(True)
+    r = torch.randn(P, 4, generator=g).cuda().requires_grad_(True)
+    o = (torch.randn(P, 1, generator=g) * 2).cuda().requires_grad_(True)
+    f = (torch.rand(P, 1, generator=g) * 0.05).cuda() if with_filter else None
+    ws = [torch.randn(P, 3, generator=g).cuda(), torch.randn(P, 4, generator=g).cuda(), torch.randn(P, 1, generator=g).cuda()]
+    so, ro, oo = fused_activations(s, r, o, f)
+    (so * ws[0]).sum().add((ro * ws[1]).sum()).add((oo * ws[2]).sum()).backward()
+    got = [so.detach(), ro.detach(), oo.detach(), s.grad.clone(), r.grad.clone(), o.grad.clone()]
+    s2, r2, o2 = [t.detach().clone().requires_grad_(True) for t in (s, r, o)]
+    rr = torch.nn.functional.normalize(r2)
+    if with_filter:
+        sc = torch.exp(s2); sq = torch.square(sc); aq = sq + torch.square(f)
+        ss = torch.sqrt(aq); oo2 = torch.sigmoid(o2) * torch.sqrt(sq.prod(dim=1) / aq.prod(dim=1))[..., None]
+    else:
+        ss = torch.exp(s2); oo2 = torch.sigmoid(o2)
+    (ss * ws[0]).sum().add((rr * ws[1]).sum()).add((oo2 * ws[2]).sum()).backward()
+    ref = [ss.detach(), rr.detach(), oo2.detach(), s2.grad, r2.grad, o2.grad]
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30)
