@@ -21,9 +21,27 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ED3DGS_DIST_BACKEND=gloo rehearses several ranks on ONE GPU (RCCL refuses duplicate devices)
+            backend = os.environ.get("ED3DGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _on_wire(t):
+    """gloo reduces host tensors; RCCL reduces device tensors in place."""
+    if dist.is_initialized() and dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu()
+    return t
+
+
+def allreduce_sum_(t):
+    """In-place SUM over ranks of a small tensor (the path's loss/psnr/count vector)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        w = _on_wire(t)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        if w is not t:
+            t.copy_(w)
+    return t
 
 
 def shard_items(n_items, rank, world):
@@ -40,9 +58,7 @@ def item_of(index, n_cams, n_frames):
 def allreduce_stats(loss_sum, psnr_sum, count, device):
     """The path's single collective: SUM of [loss, psnr, count] over ranks.  Returns a tensor of 3 floats."""
     t = torch.tensor([float(loss_sum), float(psnr_sum), float(count)], dtype=torch.float64 if device == "cpu" else torch.float32, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
+    return allreduce_sum_(t)
 
 
 def barrier():
@@ -53,5 +69,7 @@ def barrier():
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64 if device == "cpu" else torch.float32, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        w = _on_wire(t)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        t = w
     return float(t[0])
