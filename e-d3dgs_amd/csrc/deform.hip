@@ -685,7 +685,7 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
     } while (0)
 
 template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_forward_pipe_kernel(DeformDev d)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_forward_pipe_kernel(DeformDev d)
 {
     extern __shared__ float wl[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 }
 
 template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_dgrad_pipe_kernel(DeformDev d)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_dgrad_pipe_kernel(DeformDev d)
 {
     extern __shared__ float wl[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -1630,7 +1630,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         if constexpr (N <= 4) {
             if (piped) {  // weights shared through LDS by the block's four waves
                 const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
-                hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 256)), dim3(256), lds, s, d);
+                hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 512)), dim3(256), lds, s, d);
                 return;
             }
         }
@@ -1713,7 +1713,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 if (piped) {
                     const size_t lds = (size_t)2 * (2 * N + OTMAX) * 1024 * sizeof(float);
                     okp = check_hip(hipFuncSetAttribute((const void *)deform_dgrad_pipe_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size");
-                    if (okp) hipLaunchKernelGGL((deform_dgrad_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 256)), dim3(256), lds, s, d);
+                    if (okp) hipLaunchKernelGGL((deform_dgrad_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 512)), dim3(256), lds, s, d);
                     return;
                 }
             }

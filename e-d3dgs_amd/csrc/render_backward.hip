@@ -1,7 +1,12 @@
 // render_backward.hip -- K7: reverse-order traversal of one 16x16 tile per wavefront, producing per-Gaussian
 // gradient records.  Computes what CR/backward.cu:631-1016 (renderCUDA backward) computes; differences in HOW:
-//  * the suffix blends (accum_rec etc.) are advanced eagerly at the end of an iteration instead of lazily at the
-//    start of the next one (same operands, no last_* copies -> 8 fewer live registers per pixel);
+//  * the per-channel suffix blends (accum_rec, accum_alpha_rec, ...; :870-:962) are replaced by ONE per-pixel suffix sum
+//    V = sum_{j behind k} alpha_j T_j s_j, s_j = <channel values of Gaussian j at the pixel, upstream channel gradients>:
+//    (c - accum_rec) * T_k == c * T_k - U_k / (1 - alpha_k), and contracting over channels first needs a single
+//    accumulator instead of one per channel (the background term is the last layer, weight T_final);
+//  * a lane's 4 pixels are processed as two f32x2 pairs so the arithmetic issues as v_pk_fma/mul/add_f32; skipped
+//    pixels run with alpha = G = 0 (updates are the identity, contributions exact zeros) instead of selects;
+//  * sums that are linear in dy (a lane constant) are accumulated without it and scaled once per Gaussian;
 //  * the reference issues 10-25 float atomics per (pixel, Gaussian) pair; here each lane first sums its 4 pixels,
 //    the 16 (or 32) partial sums are reduced across the wavefront with a DPP butterfly that leaves sum k in lane k,
 //    and ONE 64-byte atomic wave-instruction per (tile, Gaussian) adds the record;
@@ -11,6 +16,8 @@
 #include "raster_common.h"
 
 namespace ed3 {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -100,12 +107,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     for (int p = 0; p < 4; p++) fpx[p] = (float)(px0 + p);
     const uint2 range = ranges[tile];
 
-    // ---- per-pixel state ----
-    float T[4], PB[4];                        // transmittance; -T_final * (bg . dL_dpixel)
+    // ---- per-pixel state (prologue in scalars, then packed into pixel pairs) ----
+    float T[4], V[4];                         // transmittance; suffix sum of w_j * s_j (+ T_final * bg . dL_dpixel)
     float g0[4], g1[4], g2[4], gA[4];         // dL_dpixel rgb, adjusted dL_dalpha
     float gT[4], gMT[4], gN0[4], gN1[4], gN2[4];
     float gC0[4], gC1[4], gC2[4], gM0[4], gM1[4], gM2[4];
-    float ar0[4], ar1[4], ar2[4], aa[4], at[4], an0[4], an1[4], an2[4], ac0[4], ac1[4], ac2[4];
     uint32_t last[4], maxc[4];
     {
         float al[4];
@@ -125,9 +131,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             if (!in) { al[p] = 0.f; lc[p] = 0; mc[p] = 0; g0[p] = g1[p] = g2[p] = gA[p] = 0.f; }
             last[p] = lc[p]; maxc[p] = mc[p];
             T[p] = 1.f - al[p];
-            PB[p] = -(T[p]) * (bg[0] * g0[p] + bg[1] * g1[p] + bg[2] * g2[p]);
-            ar0[p] = ar1[p] = ar2[p] = aa[p] = at[p] = an0[p] = an1[p] = an2[p] = 0.f;
-            ac0[p] = ac1[p] = ac2[p] = 0.f;
+            V[p] = T[p] * (bg[0] * g0[p] + bg[1] * g1[p] + bg[2] * g2[p]);
             gT[p] = gMT[p] = gN0[p] = gN1[p] = gN2[p] = 0.f;
             gC0[p] = gC1[p] = gC2[p] = gM0[p] = gM1[p] = gM2[p] = 0.f;
         }
@@ -188,6 +192,27 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             }
         }
     }
+    // a pixel nothing was blended into (alpha_out == 0) has 0/0 in the normalised gradients above; it takes no part in
+    // any Gaussian's gradient, and since skipped pixels are multiplied by zero rather than selected away, clear them
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (last[p] == 0) {
+            V[p] = g0[p] = g1[p] = g2[p] = gA[p] = gT[p] = gMT[p] = gN0[p] = gN1[p] = gN2[p] = 0.f;
+            gC0[p] = gC1[p] = gC2[p] = gM0[p] = gM1[p] = gM2[p] = 0.f;
+        }
+    }
+    // pixel pairs (2q, 2q+1): every per-pixel quantity below is an f32x2 so the arithmetic issues as v_pk_*_f32
+    f32x2 T2[2], V2[2], g0v[2], g1v[2], g2v[2], gAv[2], gTv[2], gMTv[2], gN0v[2], gN1v[2], gN2v[2];
+    f32x2 gC0v[2], gC1v[2], gC2v[2], gM0v[2], gM1v[2], gM2v[2], fpxv[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+#define ED3_PAIR(dst, src) dst[q] = f32x2{src[2 * q], src[2 * q + 1]}
+        ED3_PAIR(T2, T); ED3_PAIR(V2, V); ED3_PAIR(g0v, g0); ED3_PAIR(g1v, g1); ED3_PAIR(g2v, g2); ED3_PAIR(gAv, gA);
+        ED3_PAIR(gTv, gT); ED3_PAIR(gMTv, gMT); ED3_PAIR(gN0v, gN0); ED3_PAIR(gN1v, gN1); ED3_PAIR(gN2v, gN2);
+        ED3_PAIR(gC0v, gC0); ED3_PAIR(gC1v, gC1); ED3_PAIR(gC2v, gC2); ED3_PAIR(gM0v, gM0); ED3_PAIR(gM1v, gM1);
+        ED3_PAIR(gM2v, gM2); ED3_PAIR(fpxv, fpx);
+#undef ED3_PAIR
+    }
 
     // largest last-contributor of the tile: nothing behind it is blended by any pixel
     uint32_t lmax = max(max(last[0], last[1]), max(last[2], last[3]));
@@ -219,17 +244,22 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             const float4 r1 = s_rec[j * 4 + 1];          // cz, w, r, g
             const float dy = r0.y - fpy;
             const ConicRow cr = conic_row(r0.z, r0.w, r1.x, dy);
+            // skip decisions in scalars, bit-identical to the forward's; a skipped pixel continues with alpha = G = 0,
+            // which makes every update below the identity and every contribution an exact zero (no selects needed)
             float dx[4], alpha[4], G[4];
-            bool valid[4];
+            bool med[4];
             bool any_valid = false;
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 dx[p] = r0.x - fpx[p];
                 const float pw2 = conic_power2(cr, dx[p]);
-                G[p] = gauss_G(pw2);
-                alpha[p] = gauss_alpha(r1.y, G[p]);
-                valid[p] = (k < last[p]) && !(pw2 > 0.0f) && !(alpha[p] < ALPHA_MIN);
-                any_valid |= valid[p];
+                const float Gp = gauss_G(pw2);
+                const float ap = gauss_alpha(r1.y, Gp);
+                const bool vd = (k < last[p]) && !(pw2 > 0.0f) && !(ap < ALPHA_MIN);
+                any_valid |= vd;
+                alpha[p] = vd ? ap : 0.f;
+                G[p] = vd ? Gp : 0.f;
+                med[p] = vd && (k + 1u == maxc[p]);
             }
             if (!__any(any_valid)) continue;
 
@@ -239,92 +269,109 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
             if (COORD) { q0 = s_recc[j * 3 + 0]; q1 = s_recc[j * 3 + 1]; q2 = s_recc[j * 3 + 2]; }
             const float t_row = DEPTH ? (r2.z + r3.x * dy) : 0.f;
+            const float dyb = dy * r0.w, dyc = dy * r1.x;
+            float c0_row = 0.f, c1_row = 0.f, c2_row = 0.f;
+            if (COORD) { c0_row = q1.z + q0.y * dy; c1_row = q1.w + q0.w * dy; c2_row = q2.x + q1.y * dy; }
 
+            const f32x2 zero2 = {0.f, 0.f};
+            f32x2 sR = zero2, sG = zero2, sB = zero2, sTS = zero2, sRPX = zero2, sNX = zero2, sNY = zero2, sNZ = zero2;
+            f32x2 sOP = zero2, sGDX = zero2, sGDXX = zero2;
+            f32x2 sC0 = zero2, sC1 = zero2, sC2 = zero2, sC0x = zero2, sC1x = zero2, sC2x = zero2;
+            float mz = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f32x2 dx2 = {dx[2 * q], dx[2 * q + 1]};
+                const f32x2 a2 = {alpha[2 * q], alpha[2 * q + 1]};
+                const f32x2 G2 = {G[2 * q], G[2 * q + 1]};
+                const f32x2 om = 1.f - a2;
+                const f32x2 inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const f32x2 Tn = T2[q] * inv;           // T / (1 - alpha): transmittance in front of this Gaussian
+                const f32x2 wgt = a2 * Tn;              // dchannel_dcolor
+                // s = sum over channels of (channel value of this Gaussian at the pixel) * (upstream gradient of the channel)
+                f32x2 s = g0v[q] * r1.z + gAv[q];
+                s += g1v[q] * r1.w;
+                s += g2v[q] * r2.x;
+                sR += wgt * g0v[q];
+                sG += wgt * g1v[q];
+                sB += wgt * g2v[q];
+                if (COORD) {
+                    const f32x2 c0 = c0_row + q0.x * dx2, c1 = c1_row + q0.z * dx2, c2 = c2_row + q1.x * dx2;
+                    s += c0 * gC0v[q] + c1 * gC1v[q] + c2 * gC2v[q];
+                    f32x2 d0 = wgt * gC0v[q], d1 = wgt * gC1v[q], d2 = wgt * gC2v[q];
+                    d0.x += med[2 * q] ? gM0v[q].x : 0.f; d0.y += med[2 * q + 1] ? gM0v[q].y : 0.f;
+                    d1.x += med[2 * q] ? gM1v[q].x : 0.f; d1.y += med[2 * q + 1] ? gM1v[q].y : 0.f;
+                    d2.x += med[2 * q] ? gM2v[q].x : 0.f; d2.y += med[2 * q + 1] ? gM2v[q].y : 0.f;
+                    sC0 += d0; sC1 += d1; sC2 += d2;
+                    sC0x += d0 * dx2; sC1x += d1 * dx2; sC2x += d2 * dx2;
+                }
+                if (DEPTH) {
+                    const f32x2 tt = t_row + r2.w * dx2;
+                    s += tt * gTv[q];
+                    f32x2 dLdt = wgt * gTv[q];
+                    dLdt.x += med[2 * q] ? gMTv[q].x : 0.f;
+                    dLdt.y += med[2 * q + 1] ? gMTv[q].y : 0.f;
+                    sTS += dLdt;
+                    sRPX += dLdt * dx2;
+                }
+                if (GEO) {
+                    s += gN0v[q] * r3.y + gN1v[q] * r3.z + gN2v[q] * r3.w;
+                    sNX += wgt * gN0v[q];
+                    sNY += wgt * gN1v[q];
+                    sNZ += wgt * gN2v[q];
+                }
+                // dL_dalpha of CR/backward.cu:866-999 in suffix-sum form: (c - accum_rec) * T_k == c * T_k - U / (1 - alpha)
+                // with U = sum_{j behind} w_j c_j; contracted over channels, one scalar V per pixel carries all of them
+                // (and the background term, as the last "layer" of weight T_final)
+                const f32x2 dopa = Tn * s - inv * V2[q];
+                V2[q] += wgt * s;
+                T2[q] = Tn;
+                const f32x2 gd = G2 * dopa;             // -> dL_dopacity
+                const f32x2 gdx = gd * dx2;
+                sOP += gd;
+                sGDX += gdx;
+                sGDXX += gdx * dx2;
+                // |dL_dmean2D| terms need the per-pixel magnitudes
+                const f32x2 e = gd * r1.y;              // G * dL_dG
+                const f32x2 u1 = e * (dx2 * r0.z + dyb);
+                const f32x2 u2 = e * (dx2 * r0.w + dyc);
+                mz += fabsf(u1.x) * hW + fabsf(u2.x) * hH;
+                mz += fabsf(u1.y) * hW + fabsf(u2.y) * hH;
+            }
             float acc[NV];
 #pragma unroll
             for (int i = 0; i < NV; i++) acc[i] = 0.f;
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const bool vd = valid[p];
-                const float a = alpha[p];
-                const float om = 1.f - a;
-                const float inv = __builtin_amdgcn_rcpf(om);
-                const float Tn = T[p] * inv;           // T / (1 - alpha)
-                const float wgt = a * Tn;              // dchannel_dcolor
-                const bool is_med = vd && (k + 1u == maxc[p]);
-                float dopa = (r1.z - ar0[p]) * g0[p] + (r1.w - ar1[p]) * g1[p] + (r2.x - ar2[p]) * g2[p];
-                acc[G_R] += vd ? wgt * g0[p] : 0.f;
-                acc[G_G] += vd ? wgt * g1[p] : 0.f;
-                acc[G_B] += vd ? wgt * g2[p] : 0.f;
-                float ddelx_geo = 0.f, ddely_geo = 0.f;
-                float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-                if (COORD) {
-                    c0 = q1.z + q0.x * dx[p] + q0.y * dy;
-                    c1 = q1.w + q0.z * dx[p] + q0.w * dy;
-                    c2 = q2.x + q1.x * dx[p] + q1.y * dy;
-                    dopa += (c0 - ac0[p]) * gC0[p] + (c1 - ac1[p]) * gC1[p] + (c2 - ac2[p]) * gC2[p];
-                    float d0 = wgt * gC0[p] + (is_med ? gM0[p] : 0.f);
-                    float d1 = wgt * gC1[p] + (is_med ? gM1[p] : 0.f);
-                    float d2 = wgt * gC2[p] + (is_med ? gM2[p] : 0.f);
-                    d0 = vd ? d0 : 0.f; d1 = vd ? d1 : 0.f; d2 = vd ? d2 : 0.f;
-                    acc[16] += d0; acc[17] += d1; acc[18] += d2;
-                    acc[19] += d0 * dx[p]; acc[20] += d0 * dy;
-                    acc[21] += d1 * dx[p]; acc[22] += d1 * dy;
-                    acc[23] += d2 * dx[p]; acc[24] += d2 * dy;
-                    ddelx_geo += d0 * q0.x + d1 * q0.z + d2 * q1.x;
-                    ddely_geo += d0 * q0.y + d1 * q0.w + d2 * q1.y;
-                }
-                float tt = 0.f;
-                if (DEPTH) {
-                    tt = t_row + r2.w * dx[p];
-                    dopa += (tt - at[p]) * gT[p];
-                    float dLdt = wgt * gT[p] + (is_med ? gMT[p] : 0.f);
-                    dLdt = vd ? dLdt : 0.f;
-                    acc[G_TS] += dLdt;
-                    acc[G_RPX] += dLdt * dx[p];
-                    acc[G_RPY] += dLdt * dy;
-                    ddelx_geo += dLdt * r2.w;
-                    ddely_geo += dLdt * r3.x;
-                }
-                if (GEO) {
-                    dopa += (r3.y - an0[p]) * gN0[p] + (r3.z - an1[p]) * gN1[p] + (r3.w - an2[p]) * gN2[p];
-                    acc[G_NX] += vd ? wgt * gN0[p] : 0.f;
-                    acc[G_NY] += vd ? wgt * gN1[p] : 0.f;
-                    acc[G_NZ] += vd ? wgt * gN2[p] : 0.f;
-                }
-                dopa += (1.f - aa[p]) * gA[p];
-                dopa *= Tn;
-                dopa += PB[p] * inv;
-                float gd = G[p] * dopa;      // -> dL_dopacity
-                gd = vd ? gd : 0.f;
-                const float e = r1.y * gd;   // G * dL_dG
-                const float gx_ = -e * (dx[p] * r0.z + dy * r0.w);  // dL_dG * dG_ddelx
-                const float gy_ = -e * (dy * r1.x + dx[p] * r0.w);  // dL_dG * dG_ddely
-                acc[G_MX] += gx_ + ddelx_geo;
-                acc[G_MY] += gy_ + ddely_geo;
-                acc[G_MZ] += fabsf(gx_ * hW) + fabsf(gy_ * hH);
-                acc[G_CX] += e * dx[p] * dx[p];
-                acc[G_CY] += e * dx[p] * dy;
-                acc[G_CW] += e * dy * dy;
-                acc[G_OP] += gd;
-                // advance the suffix blends and the transmittance (eager form of :870,:900,:930,:949,:962)
-                T[p] = vd ? Tn : T[p];
-                ar0[p] = vd ? a * r1.z + om * ar0[p] : ar0[p];
-                ar1[p] = vd ? a * r1.w + om * ar1[p] : ar1[p];
-                ar2[p] = vd ? a * r2.x + om * ar2[p] : ar2[p];
-                aa[p] = vd ? a + om * aa[p] : aa[p];
-                if (COORD) {
-                    ac0[p] = vd ? a * c0 + om * ac0[p] : ac0[p];
-                    ac1[p] = vd ? a * c1 + om * ac1[p] : ac1[p];
-                    ac2[p] = vd ? a * c2 + om * ac2[p] : ac2[p];
-                }
-                if (DEPTH) at[p] = vd ? a * tt + om * at[p] : at[p];
-                if (GEO) {
-                    an0[p] = vd ? a * r3.y + om * an0[p] : an0[p];
-                    an1[p] = vd ? a * r3.z + om * an1[p] : an1[p];
-                    an2[p] = vd ? a * r3.w + om * an2[p] : an2[p];
-                }
+            const float OPl = sOP.x + sOP.y;
+            const float El = r1.y * OPl;                              // sum of e
+            const float Edx = r1.y * (sGDX.x + sGDX.y);               // sum of e * dx
+            const float Edxx = r1.y * (sGDXX.x + sGDXX.y);            // sum of e * dx * dx
+            acc[G_R] = sR.x + sR.y; acc[G_G] = sG.x + sG.y; acc[G_B] = sB.x + sB.y;
+            acc[G_OP] = OPl;
+            acc[G_CX] = Edxx;
+            acc[G_CY] = Edx * dy;
+            acc[G_CW] = El * dy * dy;
+            float mx = -(r0.z * Edx + dyb * El);                      // sum of dL_dG * dG_ddelx
+            float my = -(dyc * El + r0.w * Edx);
+            if (DEPTH) {
+                const float TSl = sTS.x + sTS.y;
+                acc[G_TS] = TSl;
+                acc[G_RPX] = sRPX.x + sRPX.y;
+                acc[G_RPY] = TSl * dy;
+                mx += TSl * r2.w;
+                my += TSl * r3.x;
             }
+            if (GEO) { acc[G_NX] = sNX.x + sNX.y; acc[G_NY] = sNY.x + sNY.y; acc[G_NZ] = sNZ.x + sNZ.y; }
+            if (COORD) {
+                const float C0 = sC0.x + sC0.y, C1 = sC1.x + sC1.y, C2 = sC2.x + sC2.y;
+                acc[16] = C0; acc[17] = C1; acc[18] = C2;
+                acc[19] = sC0x.x + sC0x.y; acc[20] = C0 * dy;
+                acc[21] = sC1x.x + sC1x.y; acc[22] = C1 * dy;
+                acc[23] = sC2x.x + sC2x.y; acc[24] = C2 * dy;
+                mx += C0 * q0.x + C1 * q0.z + C2 * q1.x;
+                my += C0 * q0.y + C1 * q0.w + C2 * q1.y;
+            }
+            acc[G_MX] = mx;
+            acc[G_MY] = my;
+            acc[G_MZ] = mz;
             const float z = wave_transpose_reduce<NV>(acc, lane);
             const uint32_t id = s_id[j];
             if (lane < 16) {
