@@ -97,6 +97,7 @@ struct DeformDev {
     const float *g[5], *gs[5];
     float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
     float *g_emb;
+    int store_gz;  // dgrad writes g_z (only the generic wgrad path reads it back)
     int ablate;  // diagnostic builds only: bit mask of phases to skip (timing experiments; results are then wrong)
 };
 
@@ -891,7 +892,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
 #pragma unroll
                     for (int r = 0; r < 16; r++) z[0][r] = z[0][r] > 0.f ? acc[r] : 0.f;
-                    if (gvalid) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                    if (gvalid && d.store_gz) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
 #pragma unroll
                     for (int i2 = 0; i2 < NT; i2++)
                         ga[i2] = gemm_tile_lds<1>(wb + (NT + OTMAX + i2) * 1024, z, ga[i2], lane);
@@ -1425,6 +1426,199 @@ __global__ void __launch_bounds__(256) deform_wgrad_kernel(WgradArgs a)
     if (J.db && tid < J.M) atomicAdd(J.db + tid, bsum);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// head weight gradients, W == 128: one block = (stage, head k, range of Gaussians) produces dW2_k, db2_k, dW3_k, db3_k.
+// g_z_k = (g_y_k W3_k) * (z_k > 0) is RE-FORMED here from the head's upstream gradient (<= 48 floats per Gaussian)
+// instead of being stored by the dgrad kernel and read back (512 B per Gaussian per head each way): per 32-Gaussian
+// slab the block stages relu(z_k) and a (32 x 128 each) and g_y (32 x nk) in LDS; every wave forms the two 32 x 32
+// tiles of g_z its 2 x 2 patch of dW2 needs with the Gaussian on the REGISTER index (D[i = Gaussian][j = feature]),
+// which is exactly the A-operand order of dW2 = g_z^T a when k-step kk takes Gaussian rows f(kk, h) = (kk&3) + 8(kk>>2)
+// + 4h -- the sum over the slab does not care about the order -- so g_z never touches LDS or HBM.
+// dW3 = g_y^T relu(z): wave w owns feature tile w.
+// ------------------------------------------------------------------------------------------------------------
+struct HeadJob {
+    const float *ZR, *A, *G, *G2, *W3;
+    float *dW2, *db2, *dW3, *db3;
+    int nk;
+    float gscale;
+};
+constexpr int MAXHEADJOBS = 2 * NHEAD;
+struct HeadWgradArgs {
+    int P, njobs;
+    int blk_begin[MAXHEADJOBS + 1];
+    HeadJob job[MAXHEADJOBS];
+};
+constexpr int HJ_W = 128;
+
+template <bool WIDE>
+__device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int split, int nsplit, float *lds)
+{
+    constexpr int KS3 = WIDE ? 24 : 2;       // k-steps of g_y . W3 (two head outputs per step; nk <= 48)
+    constexpr int MT3 = WIDE ? 2 : 1;        // 32-row tiles of dW3
+    constexpr int LDG = MT3 * 32 + 1;        // g_y slab row stride (odd: the column reads below are conflict-free)
+    constexpr int NG = WIDE ? 6 : 1;         // g_y elements staged per thread and slab (32 * nk / 256)
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pmi = wave >> 1, pni = wave & 1;
+    const int nk = J.nk;
+    float *zs = lds, *as = lds + 32 * HJ_W, *gs = lds + 2 * 32 * HJ_W;
+    const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int p0 = split * chunk, p1 = min(P, p0 + chunk);
+    if (p0 >= p1) return;
+    const int nslab = (p1 - p0 + 31) / 32;
+
+    for (int e = tid; e < 32 * LDG; e += 256) gs[e] = 0.f;  // pad columns stay zero
+    // W3 as the B operand of g_y . W3 for this wave's two m-tiles: lane (feature c, k-slot h) takes W3[2kk+h][feature];
+    // in registers for the narrow heads, in LDS (rows past nk zero) for the 48-wide one
+    float *w3s = gs + 32 * LDG;
+    float w3f[2][WIDE ? 1 : KS3];
+    if (WIDE) {
+        for (int e = tid; e < 2 * KS3 * HJ_W; e += 256) w3s[e] = (e / HJ_W < nk) ? J.W3[e] : 0.f;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int kk = 0; kk < KS3; kk++) {
+                const int k = 2 * kk + h;
+                w3f[t][kk] = (k < nk) ? J.W3[(size_t)k * HJ_W + (2 * pmi + t) * 32 + c] : 0.f;
+            }
+    }
+    f32x16 acc[2][2], acc3[MT3];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT3; t++) acc3[t][r] = 0.f;
+    }
+    float bsum2[2] = {0.f, 0.f}, bsum3 = 0.f;
+
+    f32x4 zv[4], av[4];
+    float gv[NG], g2v[NG];
+    const bool has_g2 = J.G2 != nullptr;
+    const int gcount = 32 * nk;
+    auto load_regs = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = tid + 256 * i, r = e >> 5, cc = (e & 31) * 4;
+            const size_t o = (size_t)min(r0 + r, p1 - 1) * HJ_W + cc;
+            zv[i] = *reinterpret_cast<const f32x4 *>(J.ZR + o);
+            av[i] = *reinterpret_cast<const f32x4 *>(J.A + o);
+        }
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int e = tid + 256 * i;
+            const size_t o = (size_t)r0 * nk + min(e, (p1 - r0) * nk - 1);
+            gv[i] = J.G[o];
+            if (has_g2) g2v[i] = J.G2[o];
+        }
+    };
+    auto store_lds = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = tid + 256 * i, r = e >> 5, cc = (e & 31) * 4;
+            *reinterpret_cast<f32x4 *>(zs + r * HJ_W + cc) = zv[i];
+            *reinterpret_cast<f32x4 *>(as + r * HJ_W + cc) = av[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int e = tid + 256 * i;
+            if (e < gcount) {
+                const int r = e / nk, cc = e - r * nk;
+                float v = gv[i];
+                if (has_g2) v += g2v[i];
+                gs[r * LDG + cc] = (r0 + r < p1) ? v * J.gscale : 0.f;   // rows past the range contribute nothing
+            }
+        }
+    };
+
+    __syncthreads();
+    load_regs(0);
+    store_lds(0);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; slab++) {
+        if (slab + 1 < nslab) load_regs(slab + 1);
+        // g_z tiles (Gaussian on the register index), masked by relu(z) > 0
+        float gz[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS3; kk++) {
+                const float wv = WIDE ? w3s[(2 * kk + h) * HJ_W + (2 * pmi + t) * 32 + c] : w3f[t][WIDE ? 0 : kk];
+                if (2 * kk < nk) d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                gz[t][r] = zs[row * HJ_W + (2 * pmi + t) * 32 + c] > 0.f ? d[r] : 0.f;
+                bsum2[t] += gz[t][r];
+            }
+        }
+        // dW2 patch: k-step kk multiplies Gaussian rows f(kk, h); dW3 tile(s): rows 2kk + h
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const int rowf = (kk & 3) + 8 * (kk >> 2) + 4 * h;
+            const float b0 = as[rowf * HJ_W + (2 * pni) * 32 + c], b1 = as[rowf * HJ_W + (2 * pni + 1) * 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[0][kk], b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[0][kk], b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[1][kk], b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[1][kk], b1, acc[1][1], 0, 0, 0);
+            const int row = 2 * kk + h;
+            const float zb = zs[row * HJ_W + wave * 32 + c];
+#pragma unroll
+            for (int t = 0; t < MT3; t++)
+                acc3[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[row * LDG + t * 32 + c], zb, acc3[t], 0, 0, 0);
+        }
+        if (tid < nk) {
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) bsum3 += gs[r * LDG + tid];
+        }
+        __syncthreads();
+        if (slab + 1 < nslab) store_lds(slab + 1);
+        __syncthreads();
+    }
+    // flush: dW2[m][n] (m = g_z feature, n = a feature), dW3[i][n] (i = head output, n = z feature)
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mi = (2 * pmi + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(J.dW2 + (size_t)mi * HJ_W + (2 * pni + u) * 32 + c, acc[t][u][r]);
+            }
+#pragma unroll
+    for (int t = 0; t < MT3; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, acc3[t][r]);
+        }
+    if (pni == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const float v = bsum2[t] + __shfl_xor(bsum2[t], 32);
+            if (h == 0) atomicAdd(J.db2 + (2 * pmi + t) * 32 + c, v);
+        }
+    }
+    if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_kernel(HeadWgradArgs a)
+{
+    extern __shared__ float hj_lds[];
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    const HeadJob &J = a.job[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
+    if (J.nk > 4) head_wgrad_body<true>(J, a.P, split, nsplit, hj_lds);
+    else head_wgrad_body<false>(J, a.P, split, nsplit, hj_lds);
+}
+
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
 struct FrameBwdArgs {
     int W, E, TD, max_emb, num_offsets, cam_no;
@@ -1674,6 +1868,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.GZ[st] = w.GZ[st]; d.GHID[st] = w.GHID[st]; }
     d.g_emb = g_embedding;
     d.ablate = getenv("ED3DGS_FB_ABLATE") ? atoi(getenv("ED3DGS_FB_ABLATE")) : 0;
+    d.store_gz = 1;
     if (!cfg->use_stage[0] && !cfg->use_stage[1]) {
         if (!check_hip(hipMemsetAsync(g_embedding, 0, (size_t)cfg->P * cfg->E * sizeof(float), s), "memset g_emb")) return ED3DGS_ERR_HIP;
         return 0;
@@ -1706,6 +1901,9 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const int nstrips = (cfg->P + 31) / 32;
         const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
         const bool piped = d.NT <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+        // head jobs (g_z re-formed inside the weight-gradient kernel): width 128, head outputs <= 48
+        const bool head_jobs = piped && cfg->W == HJ_W && 3 * cfg->n_sh <= 48 && !getenv("ED3DGS_DEFORM_GENERIC_WGRAD");
+        d.store_gz = head_jobs ? 0 : 1;
         bool okp = true;
         dispatch_nt(d.NT, [&](auto nt) {
             constexpr int N = decltype(nt)::value;
@@ -1736,6 +1934,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 }
         };
         const bool both = cfg->use_stage[0] && cfg->use_stage[1];
+        std::vector<HeadJob> hjobs;
         for (int st = 0; st < 2; st++) {
             if (!cfg->use_stage[st]) continue;
             const bool add_sub = (st == 0), add_out = (st == 1) || both || !cfg->use_stage[1];
@@ -1744,6 +1943,17 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 if (!d.enabled[k]) continue;
                 const float *G = add_out ? gg[k] : nullptr, *G2 = add_sub ? gsub[k] : nullptr;
                 if (!G) { G = G2; G2 = nullptr; }
+                if (head_jobs) {  // dW2/db2/dW3/db3 of the head in one pass, g_z re-formed on chip
+                    if (G) {
+                        HeadJob J;
+                        J.ZR = w.ZR[st] + k * PW; J.A = w.A[st]; J.G = G; J.G2 = G2; J.W3 = params[st] + pl.W3[k];
+                        J.dW2 = gparams[st] + pl.W2[k]; J.db2 = gparams[st] + pl.b2[k];
+                        J.dW3 = gparams[st] + pl.W3[k]; J.db3 = gparams[st] + pl.b3[k];
+                        J.nk = d.nk[k]; J.gscale = d.hc[k];
+                        hjobs.push_back(J);
+                    }
+                    continue;
+                }
                 if (G)  // dW3 / db3 from the upstream gradient of the head's output
                     add_job(G, G2, d.nk[k], d.nk[k], d.hc[k], w.ZR[st] + k * PW, cfg->W, cfg->W, gparams[st] + pl.W3[k],
                             cfg->W, gparams[st] + pl.b3[k]);
@@ -1780,6 +1990,26 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         }
         wa.blk_begin[wa.njobs] = nblk;
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3(nblk), dim3(256), wg_lds, s, wa);
+    }
+    if (!hjobs.empty()) {
+        // blocks per job proportional to its MFMA work per slab (g_z tiles + dW2 patch + dW3 tiles), ~2 blocks per CU
+        HeadWgradArgs ha;
+        std::memset(&ha, 0, sizeof ha);
+        ha.P = cfg->P;
+        ha.njobs = (int)hjobs.size();
+        int wsum = 0;
+        std::vector<int> wgt(ha.njobs);
+        for (int q = 0; q < ha.njobs; q++) { wgt[q] = hjobs[q].nk > 4 ? 144 : 84; wsum += wgt[q]; }
+        int nblk = 0;
+        for (int q = 0; q < ha.njobs; q++) {
+            ha.job[q] = hjobs[q];
+            ha.blk_begin[q] = nblk;
+            nblk += std::max(1, std::min((cfg->P + 127) / 128, 512 * wgt[q] / wsum));
+        }
+        ha.blk_begin[ha.njobs] = nblk;
+        const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + 48 * HJ_W) * sizeof(float);  // z, a, g_y slabs + W3
+        if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
+        hipLaunchKernelGGL(deform_head_wgrad_kernel, dim3(nblk), dim3(256), lds, s, ha);
     }
     if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
 
