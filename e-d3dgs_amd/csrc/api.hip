@@ -33,6 +33,13 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     g.scan_size = scan_temp_bytes((int)P);
     obtain(chunk, g.scan_space, g.scan_size, 128);
     obtain(chunk, g.point_offsets, P, 128);
+    obtain(chunk, g.depth_keys, P, 128);
+    obtain(chunk, g.depth_keys_sorted, P, 128);
+    obtain(chunk, g.ids, P, 128);
+    obtain(chunk, g.order, P, 128);
+    obtain(chunk, g.offsets_sorted, P, 128);
+    g.sort_size = sort_temp_bytes((int)P);
+    obtain(chunk, g.sort_space, g.sort_size, 128);
     return g;
 }
 ImageState ImageState::from_chunk(char *&chunk, size_t N, size_t T)
@@ -50,8 +57,9 @@ BinningState BinningState::from_chunk(char *&chunk, size_t R)
     BinningState b;
     obtain(chunk, b.point_list, R, 128);
     obtain(chunk, b.point_list_unsorted, R, 128);
+    obtain(chunk, b.tile_keys, R, 128);
+    obtain(chunk, b.tile_keys_unsorted, R, 128);
     obtain(chunk, b.keys, R, 128);
-    obtain(chunk, b.keys_unsorted, R, 128);
     b.sort_size = sort_temp_bytes((int)R);
     obtain(chunk, b.sort_space, b.sort_size, 128);
     return b;
@@ -166,6 +174,11 @@ int ed3dgs_rasterize_forward(
     if (!ok("preprocess")) return ED3DGS_ERR_HIP;
     if (!run_scan(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.point_offsets, P, s)) return ED3DGS_ERR_HIP;
     if (!ok("scan")) return ED3DGS_ERR_HIP;
+    // binning level 1 (binning.hip): Gaussians by depth, then the instance offsets in that order; enqueued before the
+    // read-back below so it runs under the host's wait
+    if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
+    if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
+    if (!ok("depth order")) return ED3DGS_ERR_HIP;
 
     // the one blocking read-back of the path (CR/rasterizer_impl.cu:359)
     uint32_t num_rendered_u = 0;
@@ -178,13 +191,13 @@ int ed3dgs_rasterize_forward(
     if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
     BinningState bin = BinningState::from_chunk(bin_chunk, R);
 
-    launch_duplicate_with_keys(P, geom, radii, width, height, bin.keys_unsorted, bin.point_list_unsorted, s);
+    launch_duplicate_with_keys(P, geom, radii, width, height, bin.tile_keys_unsorted, bin.point_list_unsorted, s);
     if (!ok("duplicateWithKeys")) return ED3DGS_ERR_HIP;
     const int bit = (int)higher_msb((uint32_t)T);
-    if (!run_sort(bin.sort_space, bin.sort_size, bin.keys_unsorted, bin.keys, bin.point_list_unsorted, bin.point_list, R, 32 + bit, s)) return ED3DGS_ERR_HIP;
+    if (!run_sort(bin.sort_space, bin.sort_size, bin.tile_keys_unsorted, bin.tile_keys, bin.point_list_unsorted, bin.point_list, R, bit, s)) return ED3DGS_ERR_HIP;
     if (!ok("sort")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
-    launch_identify_tile_ranges(R, bin.keys, img.ranges, s);
+    launch_identify_tile_ranges(R, bin.tile_keys, img.ranges, s);
     if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
 
     const bool pf = g_prof.on && g_prof.nf < g_prof.cap;
@@ -312,6 +325,10 @@ int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geome
     if (binning_buffer) {
         char *bc = const_cast<char *>(binning_buffer);
         BinningState b = BinningState::from_chunk(bc, R);
+        // the product path sorts 32-bit tile keys (binning.hip); the reference's 64-bit keys are composed here, for the
+        // parity tests, from the sorted tile ids and the depths of the listed Gaussians
+        launch_compose_keys(R, b.tile_keys, b.point_list, g.depths, b.keys, nullptr);
+        if (!check_hip(hipGetLastError(), "compose keys") || !check_hip(hipDeviceSynchronize(), "compose keys sync")) return ED3DGS_ERR_HIP;
         out->point_list_keys = b.keys; out->point_list = b.point_list;
     }
     return 0;

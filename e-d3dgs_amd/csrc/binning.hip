@@ -1,26 +1,40 @@
-// binning.hip -- K2 (inclusive scan of tiles_touched) and K4 (stable radix sort of (tile|depth, id) pairs).
-// Plain library primitives (rocPRIM through hipCUB); the contract is the one the reference gets from CUB:
-// exact integer scan, stable LSD radix sort on key bits [0, 32+msb(T))  (CR/rasterizer_impl.cu:355, :378-386).
+// binning.hip -- K2 (inclusive scans of tiles_touched) and K4 (stable radix sorts).
+// Plain library primitives (rocPRIM through hipCUB).  The reference sorts (tile << 32 | depth bits, id) pairs once over
+// key bits [0, 32 + msb(T)) (CR/rasterizer_impl.cu:355, :378-386): 6 onesweep passes over 12-byte pairs.  An LSD radix
+// sort is a sequence of stable passes from the low bits up, so the same permutation comes out of TWO sorts:
+//   level 1: the P Gaussians by their 32 depth bits (value = Gaussian id; tiny, P << R);
+//   level 2: the R instances, EMITTED in that depth order, by the msb(T) tile bits only (2 passes over 8-byte pairs).
+// Ties behave identically: equal depth bits keep Gaussian-id order (level 1 is stable, as the low-bit passes of the
+// reference's sort are over instances emitted in id order), equal tiles keep depth order (level 2 is stable).
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
 
 namespace ed3 {
 
+namespace {
+struct Gather {
+    const uint32_t *src;
+    __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t &i) const { return src[i]; }
+};
+}  // namespace
+
 size_t scan_temp_bytes(int P)
 {
     size_t bytes = 0;
     uint32_t *p = nullptr;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, p, p, P > 0 ? P : 1);
-    return bytes;
+    size_t bytes2 = 0;
+    hipcub::TransformInputIterator<uint32_t, Gather, const uint32_t *> it(p, Gather{p});
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes2, it, p, P > 0 ? P : 1);
+    return bytes > bytes2 ? bytes : bytes2;
 }
 
-size_t sort_temp_bytes(int R)
+size_t sort_temp_bytes(int n)
 {
     size_t bytes = 0;
-    uint64_t *k = nullptr;
-    uint32_t *v = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, v, v, R > 0 ? R : 1);
+    uint32_t *k = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, n > 0 ? n : 1);
     return bytes;
 }
 
@@ -29,11 +43,18 @@ bool run_scan(char *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, 
     return check_hip(hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, in, out, P, s), "InclusiveSum");
 }
 
-bool run_sort(char *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
-              int R, int end_bit, hipStream_t s)
+bool run_scan_gather(char *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
+                     hipStream_t s)
 {
-    if (R <= 0) return true;
-    return check_hip(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, R, 0, end_bit, s),
+    hipcub::TransformInputIterator<uint32_t, Gather, const uint32_t *> it(order, Gather{in});
+    return check_hip(hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, it, out, P, s), "InclusiveSum (depth order)");
+}
+
+bool run_sort(char *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+              int n, int end_bit, hipStream_t s)
+{
+    if (n <= 0) return true;
+    return check_hip(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, end_bit, s),
                      "SortPairs");
 }
 

@@ -31,9 +31,15 @@ struct GeometryState {
     float *cov3D;          // [P][6]
     uint8_t *clamped;      // [P]
     uint32_t *tiles_touched;
-    uint32_t *point_offsets;
+    uint32_t *point_offsets;   // inclusive scan of tiles_touched in Gaussian order (num_rendered = last element)
     char *scan_space;
     size_t scan_size;
+    // depth pre-sort (binning level 1): Gaussians ordered by view depth, and the scan of tiles_touched in THAT order
+    uint32_t *depth_keys, *depth_keys_sorted;  // depth bits (0xFFFFFFFF for culled Gaussians)
+    uint32_t *ids, *order;                     // iota, and the depth-sorted permutation
+    uint32_t *offsets_sorted;
+    char *sort_space;
+    size_t sort_size;
     static GeometryState from_chunk(char *&chunk, size_t P);
 };
 struct ImageState {
@@ -47,8 +53,9 @@ struct ImageState {
 struct BinningState {
     uint32_t *point_list;
     uint32_t *point_list_unsorted;
-    uint64_t *keys;
-    uint64_t *keys_unsorted;
+    uint32_t *tile_keys;           // tile id per instance, sorted (binning level 2: stable sort on the tile bits only)
+    uint32_t *tile_keys_unsorted;
+    uint64_t *keys;                // (tile << 32 | depth bits), composed on demand by ed3dgs_state_view_get only
     char *sort_space;
     size_t sort_size;
     static BinningState from_chunk(char *&chunk, size_t R);
@@ -69,14 +76,20 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                        const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
                        float kernel_size, int *radii, GeometryState g, hipStream_t s);
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s);
-void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint64_t *keys,
+void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint32_t *tile_keys,
                                 uint32_t *values, hipStream_t s);
-void launch_identify_tile_ranges(int R, const uint64_t *keys, uint32_t *ranges, hipStream_t s);
+void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ranges, hipStream_t s);
+void launch_compose_keys(int R, const uint32_t *tile_keys, const uint32_t *point_list, const float *depths,
+                         uint64_t *keys, hipStream_t s);
 size_t scan_temp_bytes(int P);
-size_t sort_temp_bytes(int R);
+size_t sort_temp_bytes(int n);
 bool run_scan(char *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s);
-bool run_sort(char *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
-              int R, int end_bit, hipStream_t s);
+// inclusive scan of in[order[i]]
+bool run_scan_gather(char *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
+                     hipStream_t s);
+// stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits [0, end_bit)
+bool run_sort(char *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+              int n, int end_bit, hipStream_t s);
 
 void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                            const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,

@@ -153,12 +153,14 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
     float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size, int *__restrict__ radii,
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
-    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, int gx, int gy)
+    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
+    uint32_t *__restrict__ ids, int gx, int gy)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
     int out_radius = 0;
     uint32_t out_tiles = 0;
+    uint32_t out_key = 0xFFFFFFFFu;  // culled Gaussians sort to the end of the depth order (they emit nothing)
     do {
         v3 p_orig = mk3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
         v3 p_view = xform4x3(p_orig, view);
@@ -202,6 +204,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         }
         clamped[idx] = cl;
         depths[idx] = p_view.z;
+        out_key = __float_as_uint(p_view.z);  // positive float: bit order == value order (CR/rasterizer_impl.cu:104)
         float4 *r4 = reinterpret_cast<float4 *>(rec + (size_t)idx * REC);
         r4[0] = make_float4(pix_x, pix_y, conx, cony);
         r4[1] = make_float4(conz, opacities[idx] * c2.coef, rgb.x, rgb.y);
@@ -216,6 +219,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     } while (0);
     radii[idx] = out_radius;
     tiles_touched[idx] = out_tiles;
+    depth_keys[idx] = out_key;
+    ids[idx] = (uint32_t)idx;
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means,
@@ -227,47 +232,56 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
     present[idx] = !(pv.z <= 0.2f);
 }
 
-// K3: CR/rasterizer_impl.cu:70-111
+// K3: CR/rasterizer_impl.cu:70-111, walking the Gaussians in depth order (binning.hip): thread i emits the instances
+// of Gaussian order[i] at the offset its predecessors in THAT order leave, keyed by the tile id alone
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const float *__restrict__ rec,
-                                                                  const float *__restrict__ depths,
-                                                                  const uint32_t *__restrict__ offsets,
+                                                                  const uint32_t *__restrict__ order,
+                                                                  const uint32_t *__restrict__ offsets_sorted,
                                                                   const int *__restrict__ radii, int gx, int gy,
-                                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ values)
+                                                                  uint32_t *__restrict__ tile_keys,
+                                                                  uint32_t *__restrict__ values)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t idx = order[i];
     int rad = radii[idx];
     if (rad > 0) {
-        uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
+        uint32_t off = (i == 0) ? 0 : offsets_sorted[i - 1];
         float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
         int2 rmin, rmax;
         get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
-        uint32_t dbits = __float_as_uint(depths[idx]);
         for (int y = rmin.y; y < rmax.y; y++)
             for (int x = rmin.x; x < rmax.x; x++) {
-                uint64_t key = (uint64_t)(uint32_t)(y * gx + x);
-                key <<= 32;
-                key |= dbits;
-                keys[off] = key;
-                values[off] = (uint32_t)idx;
+                tile_keys[off] = (uint32_t)(y * gx + x);
+                values[off] = idx;
                 off++;
             }
     }
 }
 
 // K5: CR/rasterizer_impl.cu:151-173
-__global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint64_t *__restrict__ keys,
+__global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint32_t *__restrict__ tile_keys,
                                                                    uint32_t *__restrict__ ranges)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
-    uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+    uint32_t currtile = tile_keys[idx];
     if (idx == 0) ranges[2 * currtile] = 0;
     else {
-        uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+        uint32_t prevtile = tile_keys[idx - 1];
         if (currtile != prevtile) { ranges[2 * prevtile + 1] = idx; ranges[2 * currtile] = idx; }
     }
     if (idx == L - 1) ranges[2 * currtile + 1] = L;
+}
+
+// the reference's 64-bit sort keys, for the parity tests' state view only
+__global__ void __launch_bounds__(256) compose_keys_kernel(int L, const uint32_t *__restrict__ tile_keys,
+                                                           const uint32_t *__restrict__ point_list,
+                                                           const float *__restrict__ depths, uint64_t *__restrict__ keys)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L) return;
+    keys[idx] = ((uint64_t)tile_keys[idx] << 32) | (uint64_t)__float_as_uint(depths[point_list[idx]]);
 }
 
 void launch_preprocess(int P, int D, int M, const float *means, const float *scales, float scale_modifier,
@@ -280,7 +294,7 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
     hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                        scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                        campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
-                       g.depths, g.cov3D, g.clamped, g.tiles_touched, gx, gy);
+                       g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy);
 }
 
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s)
@@ -288,18 +302,25 @@ void launch_mark_visible(int P, const float *means, const float *view, uint8_t *
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, view, present);
 }
 
-void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint64_t *keys,
+void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint32_t *tile_keys,
                                 uint32_t *values, hipStream_t s)
 {
     int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.depths,
-                       g.point_offsets, radii, gx, gy, keys, values);
+    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.order,
+                       g.offsets_sorted, radii, gx, gy, tile_keys, values);
 }
 
-void launch_identify_tile_ranges(int R, const uint64_t *keys, uint32_t *ranges, hipStream_t s)
+void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ranges, hipStream_t s)
 {
     if (R <= 0) return;
-    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, keys, ranges);
+    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, ranges);
+}
+
+void launch_compose_keys(int R, const uint32_t *tile_keys, const uint32_t *point_list, const float *depths,
+                         uint64_t *keys, hipStream_t s)
+{
+    if (R <= 0) return;
+    hipLaunchKernelGGL(compose_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, point_list, depths, keys);
 }
 
 }  // namespace ed3
