@@ -1640,16 +1640,29 @@ __global__ void __launch_bounds__(256) deform_frame_bwd_kernel(FrameBwdArgs a)
     const int jj = threadIdx.x & 63, og = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jj;
     const float *fs = a.fs + (size_t)s * FS_STRIDE;
-    const float *W1 = a.params[s] + a.W1_off;
-    float *dW1 = a.gparams[s] + a.W1_off;
-    const float *ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
+    const float *__restrict__ W1 = a.params[s] + a.W1_off;
+    float *__restrict__ dW1 = a.gparams[s] + a.W1_off;
+    const float *__restrict__ ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
     float gh = 0.f;
     if (j < TD) {
         const float hj = fs[j];
-        for (int o = og; o < a.W; o += 4) {
-            const float gb = ghb[o];
-            dW1[(size_t)o * ld + j] = gb * hj;
-            gh += W1[(size_t)o * ld + j] * gb;
+        // 8 rows per trip: the loads of a trip are issued together (one memory latency per trip, not per row)
+        for (int o0 = og; o0 < a.W; o0 += 32) {
+            float gb[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int o = min(o0 + 4 * u, a.W - 1);
+                gb[u] = ghb[o];
+                wv[u] = W1[(size_t)o * ld + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int o = o0 + 4 * u;
+                if (o < a.W) {
+                    dW1[(size_t)o * ld + j] = gb[u] * hj;
+                    gh += wv[u] * gb[u];
+                }
+            }
         }
     }
     s_gh[og][jj] = gh;
