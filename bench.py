@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-operand MFMA peak (MI355X_MICROARCH.md, matrix-core table)
 WORKLOADS = {
     "C3": dict(P=200_000, W=1920, H=1080, cams=8, frames=50, deform=True,
                name="C3: 200k Gaussians, 8 cams x 50 timesteps, 1080p, deform MLP W=128 D=1, depth+normal (FTT)"),
@@ -204,17 +205,29 @@ def main():
     _C.KEEP_LAST = False
     _C.LAST.clear()
 
-    # ---- timed: exactly K steps ----
+    # ---- per-kernel table: an instrumented, UNTIMED pass (five event pairs per step cost stream time) ----
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0x1F))
+    for k in range(a.steps):
+        step(item_at(k))
+    torch.cuda.synchronize()
+    tab_ms, tab_n = (ctypes.c_double * 5)(), (ctypes.c_int * 5)()
+    L.ed3dgs_profile_end_slots(tab_ms, tab_n)
+    tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(5)]
+    dom = max(range(5), key=lambda i: tab_avg[i])
+
+    # ---- timed: exactly K steps; events only around the dominant kernel and K7 ----
     torch.cuda.synchronize(); D.barrier()
     log("timed region")
-    L.ed3dgs_profile_begin(ctypes.c_int(a.steps + 4))
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint((1 << dom) | 2))
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(item_at(k))
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
-    f_ms, f_n, b_ms, b_n = ctypes.c_double(), ctypes.c_int(), ctypes.c_double(), ctypes.c_int()
-    L.ed3dgs_profile_end(ctypes.byref(f_ms), ctypes.byref(f_n), ctypes.byref(b_ms), ctypes.byref(b_n))
+    slot_ms, slot_n = (ctypes.c_double * 5)(), (ctypes.c_int * 5)()
+    L.ed3dgs_profile_end_slots(slot_ms, slot_n)
+    # K6, K7, deform fwd, deform dgrad, deform wgrad: timed-region events where taken, else the instrumented pass
+    avg_ms = [slot_ms[i] / slot_n[i] if slot_n[i] else tab_avg[i] for i in range(5)]
     dt = D.max_over_ranks(dt, device)
 
     log("timed region done: %.3f ms/step" % (dt / a.steps * 1e3))
@@ -234,18 +247,54 @@ def main():
     mean = lambda v: sum(v) / max(len(v), 1)
     bytes_k7 = 128.0 * mean(reff) + 68.0 * HW + 8.0 * T   # FTT: (g_b + 4a) R_eff + r HW + 8T  
     bytes_k6 = 68.0 * mean(reff) + 56.0 * HW + 8.0 * T
-    k7_ms = b_ms.value / max(b_n.value, 1)
-    k6_ms = f_ms.value / max(f_n.value, 1)
+    k6_ms, k7_ms, dfw_ms, ddg_ms, dwg_ms = avg_ms
     ach = bytes_k7 / (k7_ms * 1e-3) / 1e9 if k7_ms > 0 else 0.0
-    traffic = None
+    pmc = {}
     prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
             if pj.get("workload") == a.workload:
-                traffic = pj.get("render_backward_hbm_bytes_per_launch")
+                pmc = pj.get("hbm_bytes_per_launch", {})
         except Exception:
-            traffic = None
+            pmc = {}
+    # deformation MLP, algorithmic flops per Gaussian with the per-frame temporal row hoisted (SURVEY 8d counts the
+    # un-hoisted 288-wide first layer: 0.505 MFLOP; the 256 broadcast inputs are one GEMV per FRAME here)
+    from ed3dgs_amd.model import default_hyper
+    hy = default_hyper()
+    Wn, En = int(hy.net_width), int(hy.gaussian_embedding_dim)
+    macs = 2 * (En * Wn + 5 * Wn * Wn + Wn * (3 + 3 + 4 + 1 + 48)) if wl.get("deform", True) else 0
+    flops = 2.0 * macs * wl["P"]          # per launch: forward == data-gradient == weight-gradient contraction count
+    tf = lambda ms: flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    t6, t7, tfw, tdg, twg = tab_avg
+    kernels = {
+        "_source": "separate instrumented pass of the same %d steps (event pairs around all five kernels), not the timed region" % a.steps,
+        "render_forward_kernel<false,true> (K6)": {"avg_launch_ms": t6, "launches": tab_n[0], "bound": "valu", "GBps_algorithmic": bytes_k6 / (t6 * 1e-3) / 1e9 if t6 > 0 else 0.0},
+        "render_backward_kernel<false,true> (K7)": {"avg_launch_ms": t7, "launches": tab_n[1], "bound": "valu", "GBps_algorithmic": bytes_k7 / (t7 * 1e-3) / 1e9 if t7 > 0 else 0.0},
+        "deform_forward_pipe_kernel<4>": {"avg_launch_ms": tfw, "launches": tab_n[2], "bound": "mfma", "TFLOPs_algorithmic": tf(tfw)},
+        "deform_dgrad_pipe_kernel<4>": {"avg_launch_ms": tdg, "launches": tab_n[3], "bound": "mfma", "TFLOPs_algorithmic": tf(tdg),
+                                        "note": "also re-runs the forward contractions (activations are not kept): executes 2x the algorithmic flops"},
+        "deform_head_wgrad_kernel + deform_wgrad_kernel": {"avg_launch_ms": twg, "launches": tab_n[4], "bound": "mfma", "TFLOPs_algorithmic": tf(twg)},
+    }
+    roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+               "traffic": pmc.get("render_backward_kernel"),
+               "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1],
+               "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
+               "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
+                       "reported as defined there, next to the pair rate"}
+    if dom >= 2 and macs:
+        name = ["", "", "deform_forward_pipe_kernel<4>", "deform_dgrad_pipe_kernel<4>", "deform_head_wgrad_kernel + deform_wgrad_kernel"][dom]
+        roof = {"bound": "mfma", "kernel": name, "achieved": tf(avg_ms[dom]), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": tf(avg_ms[dom]) / MFMA_F32_PEAK_TFLOPS,
+                "traffic": pmc.get(name.split("<")[0].split(" ")[0]),
+                "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
+                "note": "dominant kernel of the step by time; fp32 operands on v_mfma_f32_32x32x2f32 (dense f32 MFMA peak "
+                        "157.3 TFLOP/s); algorithmic flops = 2 * %d MAC per Gaussian" % macs}
+        if dom == 3:
+            roof["note"] += "; the kernel re-runs the forward contractions as well, so it executes twice this count"
+    else:
+        roof = roof_k7
     res = {
         "metric": "train iters/sec @200k Gaussians 1080p (fwd+bwd of render() incl. deformation MLP)",
         "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -256,14 +305,9 @@ def main():
                    "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
         "render_fps": world * a.steps / dt_r,
         "render_fps_note": "forward only, all outputs (coord+depth+normal), torch.no_grad, incl. deformation",
-        "roofline": {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": b_n.value,
-                     "forward_kernel_avg_launch_ms": k6_ms,
-                     "forward_kernel_GBps": bytes_k6 / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else 0.0,
-                     "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
-                     "note": "K7 is VALU/LDS-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM "
-                             "fraction is reported as defined there, next to the pair rate"},
+        "roofline": roof,
+        "roofline_tile_backward": roof_k7,
+        "kernels": kernels,
     }
     if world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (bounded sample, ~15-30 s)")

@@ -76,14 +76,22 @@ static uint32_t higher_msb(uint32_t n)
 
 static inline size_t tiles_of(int W, int H) { return (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
 
-// ---- optional kernel timing (bench.py): event pairs around the two tile kernels ----
+// ---- optional kernel timing (bench.py): event pairs around the dominant kernels, one slot per kernel ----
 struct Profiler {
     bool on = false;
-    int cap = 0, nf = 0, nb = 0;
-    std::vector<hipEvent_t> f0, f1, b0, b1;
+    int cap = 0;
+    unsigned mask = 0;
+    int n[ED3DGS_PROF_SLOTS] = {0};
+    std::vector<hipEvent_t> e0[ED3DGS_PROF_SLOTS], e1[ED3DGS_PROF_SLOTS];
 };
 static Profiler g_prof;
-static void prof_mark(std::vector<hipEvent_t> &ev, int idx, hipStream_t s) { (void)hipEventRecord(ev[idx], s); }
+bool prof_start(int slot, hipStream_t s)
+{
+    if (!g_prof.on || !(g_prof.mask >> slot & 1u) || g_prof.n[slot] >= g_prof.cap) return false;
+    (void)hipEventRecord(g_prof.e0[slot][g_prof.n[slot]], s);
+    return true;
+}
+void prof_stop(int slot, hipStream_t s) { (void)hipEventRecord(g_prof.e1[slot][g_prof.n[slot]++], s); }
 
 struct StageCheck {
     bool debug; hipStream_t s;
@@ -200,12 +208,11 @@ int ed3dgs_rasterize_forward(
     launch_identify_tile_ranges(R, bin.tile_keys, img.ranges, s);
     if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
 
-    const bool pf = g_prof.on && g_prof.nf < g_prof.cap;
-    if (pf) prof_mark(g_prof.f0, g_prof.nf, s);
+    const bool pf = prof_start(ED3DGS_PROF_TILE_FORWARD, s);
     launch_render_forward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
                           background, require_coord != 0, require_depth != 0, out_color, out_coord, out_mcoord,
                           out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img, s);
-    if (pf) prof_mark(g_prof.f1, g_prof.nf++, s);
+    if (pf) prof_stop(ED3DGS_PROF_TILE_FORWARD, s);
     if (!ok("render")) return ED3DGS_ERR_HIP;
     return R;
 }
@@ -252,13 +259,12 @@ int ed3dgs_rasterize_backward(
     if (!check_hip(hipMemsetAsync(grec, 0, zero_bytes, s), "memset gradient records")) return ED3DGS_ERR_HIP;
 
     if (R > 0) {
-        const bool pb = g_prof.on && g_prof.nb < g_prof.cap;
-        if (pb) prof_mark(g_prof.b0, g_prof.nb, s);
+        const bool pb = prof_start(ED3DGS_PROF_TILE_BACKWARD, s);
         launch_render_backward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
                                background, require_coord != 0, require_depth != 0, alphas, normalmap, img, dL_dpix,
                                dL_dpix_coord, dL_dpix_mcoord, dL_dpix_depth, dL_dpix_mdepth, dL_dalphas,
                                dL_dpix_normal, grec, grec_coord, s);
-        if (pb) prof_mark(g_prof.b1, g_prof.nb++, s);
+        if (pb) prof_stop(ED3DGS_PROF_TILE_BACKWARD, s);
         if (!ok("render backward")) return ED3DGS_ERR_HIP;
     }
     launch_preprocess_backward(P, D, M, means3D, radii, shs, scales, rotations, scale_modifier, cov3D_precomp,
@@ -271,30 +277,55 @@ int ed3dgs_rasterize_backward(
 
 int ed3dgs_profile_begin(int max_samples)
 {
+    return ed3dgs_profile_begin_slots(max_samples, 1u << ED3DGS_PROF_TILE_FORWARD | 1u << ED3DGS_PROF_TILE_BACKWARD);
+}
+
+int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask)
+{
     if (g_prof.on || max_samples <= 0) { set_error("ed3dgs_profile_begin: already active or bad size"); return ED3DGS_ERR_INVALID; }
     g_prof = Profiler();
     g_prof.cap = max_samples;
-    for (auto *v : {&g_prof.f0, &g_prof.f1, &g_prof.b0, &g_prof.b1}) {
-        v->resize(max_samples);
-        for (auto &e : *v) if (!check_hip(hipEventCreate(&e), "hipEventCreate")) return ED3DGS_ERR_HIP;
-    }
+    g_prof.mask = slot_mask;
+    for (int k = 0; k < ED3DGS_PROF_SLOTS; k++)
+        for (auto *v : {&g_prof.e0[k], &g_prof.e1[k]}) {
+            if (!(slot_mask >> k & 1u)) continue;
+            v->resize(max_samples);
+            for (auto &e : *v) if (!check_hip(hipEventCreate(&e), "hipEventCreate")) return ED3DGS_ERR_HIP;
+        }
     g_prof.on = true;
+    return 0;
+}
+
+int ed3dgs_profile_end_slots(double *ms_total, int *launches)
+{
+    if (!g_prof.on) { set_error("ed3dgs_profile_end: not active"); return ED3DGS_ERR_INVALID; }
+    g_prof.on = false;
+    for (int k = 0; k < ED3DGS_PROF_SLOTS; k++) {
+        double t = 0;
+        for (int i = 0; i < g_prof.n[k]; i++) {
+            float ms = 0;
+            (void)hipEventSynchronize(g_prof.e1[k][i]);
+            (void)hipEventElapsedTime(&ms, g_prof.e0[k][i], g_prof.e1[k][i]);
+            t += ms;
+        }
+        if (ms_total) ms_total[k] = t;
+        if (launches) launches[k] = g_prof.n[k];
+        for (auto *v : {&g_prof.e0[k], &g_prof.e1[k]}) for (auto &e : *v) (void)hipEventDestroy(e);
+    }
+    g_prof = Profiler();
     return 0;
 }
 
 int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches)
 {
-    if (!g_prof.on) { set_error("ed3dgs_profile_end: not active"); return ED3DGS_ERR_INVALID; }
-    g_prof.on = false;
-    double tf = 0, tb = 0;
-    for (int i = 0; i < g_prof.nf; i++) { float ms = 0; (void)hipEventSynchronize(g_prof.f1[i]); (void)hipEventElapsedTime(&ms, g_prof.f0[i], g_prof.f1[i]); tf += ms; }
-    for (int i = 0; i < g_prof.nb; i++) { float ms = 0; (void)hipEventSynchronize(g_prof.b1[i]); (void)hipEventElapsedTime(&ms, g_prof.b0[i], g_prof.b1[i]); tb += ms; }
-    if (fwd_ms_total) *fwd_ms_total = tf;
-    if (fwd_launches) *fwd_launches = g_prof.nf;
-    if (bwd_ms_total) *bwd_ms_total = tb;
-    if (bwd_launches) *bwd_launches = g_prof.nb;
-    for (auto *v : {&g_prof.f0, &g_prof.f1, &g_prof.b0, &g_prof.b1}) for (auto &e : *v) (void)hipEventDestroy(e);
-    g_prof = Profiler();
+    double ms[ED3DGS_PROF_SLOTS];
+    int n[ED3DGS_PROF_SLOTS];
+    const int rc = ed3dgs_profile_end_slots(ms, n);
+    if (rc < 0) return rc;
+    if (fwd_ms_total) *fwd_ms_total = ms[ED3DGS_PROF_TILE_FORWARD];
+    if (fwd_launches) *fwd_launches = n[ED3DGS_PROF_TILE_FORWARD];
+    if (bwd_ms_total) *bwd_ms_total = ms[ED3DGS_PROF_TILE_BACKWARD];
+    if (bwd_launches) *bwd_launches = n[ED3DGS_PROF_TILE_BACKWARD];
     return 0;
 }
 

@@ -23,6 +23,9 @@ enum { G_R = 0, G_G, G_B, G_TS, G_RPX, G_RPY, G_NX, G_NY, G_NZ, G_MX, G_MY, G_MZ
 
 void set_error(const std::string &msg);
 bool check_hip(hipError_t e, const char *what);
+// bench.py's kernel timing (api.hip): true if a sample was opened on slot (then call prof_stop after the launches)
+bool prof_start(int slot, hipStream_t s);
+void prof_stop(int slot, hipStream_t s);
 
 struct GeometryState {
     float *rec;            // [P][16]

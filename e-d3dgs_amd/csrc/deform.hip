@@ -1832,6 +1832,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     const int nstrips = (cfg->P + 31) / 32;
     const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
     const bool piped = d.NT <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+    const bool pf = prof_start(ED3DGS_PROF_DEFORM_FORWARD, s);
     dispatch_nt(d.NT, [&](auto nt) {
         constexpr int N = decltype(nt)::value;
         if constexpr (N <= 4) {
@@ -1843,6 +1844,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         }
         hipLaunchKernelGGL((deform_forward_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
     });
+    if (pf) prof_stop(ED3DGS_PROF_DEFORM_FORWARD, s);
     if (!check_hip(hipGetLastError(), "deform forward")) return ED3DGS_ERR_HIP;
     return 0;
 }
@@ -1918,6 +1920,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const bool head_jobs = piped && cfg->W == HJ_W && 3 * cfg->n_sh <= 48 && !getenv("ED3DGS_DEFORM_GENERIC_WGRAD");
         d.store_gz = head_jobs ? 0 : 1;
         bool okp = true;
+        const bool pd = prof_start(ED3DGS_PROF_DEFORM_DGRAD, s);
         dispatch_nt(d.NT, [&](auto nt) {
             constexpr int N = decltype(nt)::value;
             if constexpr (N <= 4) {
@@ -1930,10 +1933,12 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
             }
             hipLaunchKernelGGL((deform_dgrad_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
         });
+        if (pd) prof_stop(ED3DGS_PROF_DEFORM_DGRAD, s);
         if (!okp) return ED3DGS_ERR_HIP;
         if (!check_hip(hipGetLastError(), "deform dgrad")) return ED3DGS_ERR_HIP;
 
         // weight gradients: jobs of at most 128 x 128 (one block tile), launched in batches of MAXJOBS
+        const bool pw = prof_start(ED3DGS_PROF_DEFORM_WGRAD, s);
         std::vector<WgradJob> jobs;
         auto add_job = [&](const float *G, const float *G2, int ldg, int M, float gscale, const float *X, int ldx, int N,
                            float *dW, int ldd, float *db) {
@@ -2024,6 +2029,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
         hipLaunchKernelGGL(deform_head_wgrad_kernel, dim3(nblk), dim3(256), lds, s, ha);
     }
+    if (pw) prof_stop(ED3DGS_PROF_DEFORM_WGRAD, s);
     if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
 
     }

@@ -50,7 +50,7 @@ def lib():
               "ed3dgs_deform_param_count", "ed3dgs_deform_workspace_bytes"):
         getattr(L, n).restype = C.c_size_t
     for n in ("ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible", "ed3dgs_state_view_get",
-              "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_activations_forward",
+              "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
               "ed3dgs_activations_backward"):
         getattr(L, n).restype = C.c_int
     _lib = L
@@ -61,7 +61,7 @@ EXPORTS = (
     "ed3dgs_last_error", "ed3dgs_abi_version", "ed3dgs_geometry_bytes", "ed3dgs_image_bytes", "ed3dgs_binning_bytes",
     "ed3dgs_backward_workspace_bytes", "ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible",
     "ed3dgs_state_view_get", "ed3dgs_deform_param_count", "ed3dgs_deform_workspace_bytes", "ed3dgs_deform_forward",
-    "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_activations_forward",
+    "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
     "ed3dgs_activations_backward")
 
 

@@ -142,6 +142,18 @@ int ed3dgs_activations_backward(int P, const float *scales_log, const float *rot
  * kernel durations in milliseconds and the launch counts.  Not part of the data path. */
 int ed3dgs_profile_begin(int max_samples);
 int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches);
+/* Same, for every timed kernel: arrays of ED3DGS_PROF_SLOTS entries indexed by the slots below. */
+enum {
+    ED3DGS_PROF_TILE_FORWARD = 0,   /* K6 render_forward_kernel */
+    ED3DGS_PROF_TILE_BACKWARD = 1,  /* K7 render_backward_kernel */
+    ED3DGS_PROF_DEFORM_FORWARD = 2, /* deformation MLP forward kernel */
+    ED3DGS_PROF_DEFORM_DGRAD = 3,   /* deformation MLP data-gradient kernel */
+    ED3DGS_PROF_DEFORM_WGRAD = 4,   /* deformation MLP weight-gradient kernels (head + trunk launches together) */
+    ED3DGS_PROF_SLOTS = 5
+};
+int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask);  /* bit k = time slot k; every event pair costs
+                                                                        * stream time, so time few kernels at once */
+int ed3dgs_profile_end_slots(double *ms_total, int *launches);
 
 /* ---------------- deformation MLP (scene/deformation.py) ---------------- */
 /*
