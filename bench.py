@@ -272,8 +272,8 @@ def main():
         "render_forward_kernel<false,true> (K6)": {"avg_launch_ms": t6, "launches": tab_n[0], "bound": "valu", "GBps_algorithmic": bytes_k6 / (t6 * 1e-3) / 1e9 if t6 > 0 else 0.0},
         "render_backward_kernel<false,true> (K7)": {"avg_launch_ms": t7, "launches": tab_n[1], "bound": "valu", "GBps_algorithmic": bytes_k7 / (t7 * 1e-3) / 1e9 if t7 > 0 else 0.0},
         "deform_forward_pipe_kernel<4>": {"avg_launch_ms": tfw, "launches": tab_n[2], "bound": "mfma", "TFLOPs_algorithmic": tf(tfw)},
-        "deform_dgrad_pipe_kernel<4>": {"avg_launch_ms": tdg, "launches": tab_n[3], "bound": "mfma", "TFLOPs_algorithmic": tf(tdg),
-                                        "note": "also re-runs the forward contractions (activations are not kept): executes 2x the algorithmic flops"},
+        "deform_dgrad_kept_kernel<4>": {"avg_launch_ms": tdg, "launches": tab_n[3], "bound": "mfma", "TFLOPs_algorithmic": tf(tdg),
+                                        "note": "activations kept by the forward launch (3 KB per Gaussian and stage), nothing re-formed"},
         "deform_head_wgrad_kernel + deform_wgrad_kernel": {"avg_launch_ms": twg, "launches": tab_n[4], "bound": "mfma", "TFLOPs_algorithmic": tf(twg)},
     }
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
@@ -284,15 +284,16 @@ def main():
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
                        "reported as defined there, next to the pair rate"}
     if dom >= 2 and macs:
-        name = ["", "", "deform_forward_pipe_kernel<4>", "deform_dgrad_pipe_kernel<4>", "deform_head_wgrad_kernel + deform_wgrad_kernel"][dom]
+        name = ["", "", "deform_forward_pipe_kernel<4>", "deform_dgrad_kept_kernel<4>", "deform_head_wgrad_kernel + deform_wgrad_kernel"][dom]
         roof = {"bound": "mfma", "kernel": name, "achieved": tf(avg_ms[dom]), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": tf(avg_ms[dom]) / MFMA_F32_PEAK_TFLOPS,
                 "traffic": pmc.get(name.split("<")[0].split(" ")[0]),
                 "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
                 "note": "dominant kernel of the step by time; fp32 operands on v_mfma_f32_32x32x2f32 (dense f32 MFMA peak "
                         "157.3 TFLOP/s); algorithmic flops = 2 * %d MAC per Gaussian" % macs}
-        if dom == 3:
-            roof["note"] += "; the kernel re-runs the forward contractions as well, so it executes twice this count"
+        if dom == 4:
+            roof["note"] += ("; the head kernel also re-forms g_z = (g_y W3) * (z > 0) per slab and pads the narrow heads' "
+                             "dW3 to 32 rows, so it executes ~1.3x this count")
     else:
         roof = roof_k7
     res = {

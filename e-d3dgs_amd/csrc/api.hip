@@ -110,7 +110,7 @@ using namespace ed3;
 extern "C" {
 
 const char *ed3dgs_last_error(void) { return g_error.c_str(); }
-int ed3dgs_abi_version(void) { return 1; }
+int ed3dgs_abi_version(void) { return 2; }
 
 size_t ed3dgs_geometry_bytes(int P)
 {

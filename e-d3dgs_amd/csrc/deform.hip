@@ -97,6 +97,7 @@ struct DeformDev {
     const float *g[5], *gs[5];
     float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
     float *g_emb;
+    int keep;      // forward writes a = relu(hid) and relu(z_k) for the backward (activations kept instead of re-formed)
     int store_gz;  // dgrad writes g_z (only the generic wgrad path reads it back)
     int ablate;  // diagnostic builds only: bit mask of phases to skip (timing experiments; results are then wrong)
 };
@@ -731,6 +732,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         acc = gemm_tile_lds<1>(wb + nt * 1024, eb, acc, lane);
 #pragma unroll
                         for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r], 0.f);
+                        if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
                     }
                     PIPE_ADVANCE();
                 }
@@ -748,6 +750,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         float z[1][16];
 #pragma unroll
                         for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                        if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                         y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
                         if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
                         PIPE_ADVANCE();
@@ -917,6 +920,176 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// data gradient with KEPT activations: the forward launch of the same frame stored a = relu(hid) and relu(z_k)
+// (DeformDev::keep), so nothing of the forward is re-formed here: per (head, tile) the relu(z) tile is read back (the
+// next tile's read is issued before the current tile's MFMAs), g_z = (W3^T g_y) masked, g_a += W2^T g_z; then
+// g_hid = g_a masked by a > 0 (stored for dW1) and g_emb = W1[:, TD:]^T g_hid.  Weight chunks are the [F3T | F2T]
+// tails of the backward chunk layout (frag_layout), then the transposed trunk.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+struct ChunkSeqKept {
+    int s, e, nt;   // e = index into the enabled heads; e == n_en: transposed trunk chunk
+    int n_en;
+    uint32_t en_pack;   // enabled head ids, 4 bits each (a runtime-indexed array would live in scratch)
+    __device__ __forceinline__ void init(const DeformDev &d)
+    {
+        s = d.use_stage[0] ? 0 : 1; e = 0; nt = 0; n_en = 0; en_pack = 0;
+        for (int k = 0; k < NHEAD; k++) if (d.enabled[k]) en_pack |= (uint32_t)k << (4 * n_en++);
+    }
+    __device__ __forceinline__ const float *next(const DeformDev &d)
+    {
+        const int n_chunks = 1 + NHEAD * NT + 1;
+        const size_t chb = (size_t)(2 * NT + OTMAX) * 1024;
+        const float *base = d.frag[s] + d.fl.CH;
+        const float *p = (e < n_en) ? base + (size_t)(1 + (int)(en_pack >> (4 * e) & 15u) * NT + nt) * chb + NT * 1024 : base + (size_t)(n_chunks - 1) * chb;
+        if (e < n_en && nt + 1 < NT) { nt++; return p; }
+        nt = 0;
+        if (e < n_en) { e++; return p; }
+        e = 0;
+        s = (s == 0 && d.use_stage[1]) ? 1 : (d.use_stage[0] ? 0 : 1);
+        return p;
+    }
+};
+#define ED3_CHUNK_PIPE_KEPT(NT_)                                                                   \
+    constexpr int PIPE_CHF = ((NT_) + OTMAX) * 1024;                                              \
+    constexpr int PIPE_NF4 = PIPE_CHF / 4 / 256;                                                  \
+    f32x4 pipe_st[PIPE_NF4];                                                                      \
+    ChunkSeqKept<NT_> pipe_seq;                                                                   \
+    int pipe_n = 0, pipe_total = 0;
+
+__device__ __forceinline__ void load_tile_rows4(f32x4 (&v)[4], const float *__restrict__ M, int ld, int g, int nt, int h)
+{
+    const f32x4 *row = reinterpret_cast<const f32x4 *>(M + (size_t)g * ld + nt * 32 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = row[2 * q];
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_dgrad_kept_kernel(DeformDev d)
+{
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_bi = (d.P + 127) / 128;
+    const int shw = 3 * d.n_sh;
+    const bool both = d.use_stage[0] && d.use_stage[1];
+    int n_en = 0;
+    uint32_t en_pack = 0;
+    for (int k = 0; k < NHEAD; k++) if (d.enabled[k]) en_pack |= (uint32_t)k << (4 * n_en++);
+#define EN_K(e_) ((int)(en_pack >> (4 * (e_)) & 15u))
+    const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (n_en * NT + 1);
+    const int my_iters = (n_bi > (int)blockIdx.x) ? (n_bi - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const size_t PW = (size_t)d.P * d.W;
+    ED3_CHUNK_PIPE_KEPT(NT)
+    PIPE_START(my_iters * per_iter);
+    for (int bi = blockIdx.x; bi < n_bi; bi += gridDim.x) {
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        f32x16 ge;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ge[r] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (!d.use_stage[s]) continue;
+            const bool add_sub = (s == 0);
+            const bool add_out = (s == 1) || both || !d.use_stage[1];
+            f32x16 ga[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
+            f32x4 zn[4];
+            if (n_en > 0) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(0) * PW, d.W, g, 0, h);
+#pragma unroll 1
+            for (int e = 0; e < n_en; e++) {
+                const int k = EN_K(e);
+                const float hc = d.hc[k];
+                const int nk = d.nk[k];
+                float gy[OTMAX][16];
+#pragma unroll
+                for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
+                if (k < 4) {
+                    if (h == 0) {
+                        for (int j = 0; j < nk; j++) {
+                            float v = 0.f;
+                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
+                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
+                            gy[0][j] = v * hc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) {
+                        const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                        float4 v = make_float4(0, 0, 0, 0);
+                        if (feat < shw) {
+                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        }
+                        const int ot = cc >> 2, kk0 = 4 * (cc & 3);
+                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                    }
+                }
+#pragma unroll 1
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x4 zc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) zc[q] = zn[q];
+                    {   // read of the next relu(z) tile flies under this tile's MFMAs
+                        const int e2 = (nt + 1 < NT) ? e : e + 1, nt2 = (nt + 1 < NT) ? nt + 1 : 0;
+                        if (e2 < n_en) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(e2) * PW, d.W, g, nt2, h);
+                    }
+                    const float *wb = PIPE_CUR();
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    if (k < 4) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[(ot * 16 + kk) * 64 + lane], gy[ot][kk], acc, 0, 0, 0);
+                    }
+                    float z[1][16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[0][r] = zc[r >> 2][r & 3] > 0.f ? acc[r] : 0.f;
+#pragma unroll
+                    for (int i2 = 0; i2 < NT; i2++)
+                        ga[i2] = gemm_tile_lds<1>(wb + (OTMAX + i2) * 1024, z, ga[i2], lane);
+                    PIPE_ADVANCE();
+                }
+            }
+            float gh[NT][16];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                f32x4 av[4];
+                load_tile_rows4(av, d.A[s], d.W, g, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; r++) gh[nt][r] = av[r >> 2][r & 3] > 0.f ? ga[nt][r] : 0.f;
+                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh[nt]);
+            }
+            ge = gemm_tile_lds<NT>(PIPE_CUR(), gh, ge, lane);
+            PIPE_ADVANCE();
+        }
+        if (gvalid) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = ge[r];
+            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+        }
+    }
+}
+
+#undef EN_K
 
 // ------------------------------------------------------------------------------------------------------------
 // fused backward (W <= 128): head-specialised blocks.
@@ -1788,6 +1961,13 @@ static void dispatch_nt(int NT, F f)
 
 using namespace ed3;
 
+// the kept-activation backward exists for the LDS-pipelined, head-job configuration (width 128, embedding 32)
+static bool can_keep(const ed3dgs_deform_cfg *c)
+{
+    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48 && !getenv("ED3DGS_DEFORM_NO_PIPE") &&
+           !getenv("ED3DGS_DEFORM_GENERIC_WGRAD") && !getenv("ED3DGS_DEFORM_FUSED_BWD");
+}
+
 extern "C" {
 
 size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *cfg)
@@ -1807,7 +1987,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
                           const float *rot, const float *opacity, const float *sh, float *out_xyz, float *out_scales,
                           float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
                           float *sub_rot, float *sub_opacity, float *sub_sh, char *workspace, size_t workspace_bytes,
-                          void *stream)
+                          int keep_activations, void *stream)
 {
     if (!validate(cfg, "ed3dgs_deform_forward")) return ED3DGS_ERR_INVALID;
     if (cfg->P == 0) return 0;
@@ -1816,15 +1996,18 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && !params[s]) { set_error("ed3dgs_deform_forward: null params"); return ED3DGS_ERR_INVALID; }
     const bool have_sub = sub_xyz && sub_scales && sub_rot && sub_opacity && sub_sh;
     if (!have_sub && (sub_xyz || sub_scales || sub_rot || sub_opacity || sub_sh)) { set_error("ed3dgs_deform_forward: sub_* must be all set or all NULL"); return ED3DGS_ERR_INVALID; }
-    if (workspace_bytes < carve(cfg, false, nullptr, nullptr)) { set_error("ed3dgs_deform_forward: workspace too small"); return ED3DGS_ERR_INVALID; }
+    const bool keep = keep_activations && can_keep(cfg);
+    if (workspace_bytes < carve(cfg, keep, nullptr, nullptr)) { set_error("ed3dgs_deform_forward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
-    carve(cfg, false, workspace, &w);
+    carve(cfg, keep, workspace, &w);   // keep: the backward's carve, so that A / ZR sit where the backward reads them
     if (!run_prep(cfg, table, offsets, params, w, false, s)) return ED3DGS_ERR_HIP;
     DeformDev d;
     std::memset(&d, 0, sizeof d);
     fill_dev(cfg, d, false);
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
+    d.keep = keep ? 1 : 0;
+    if (keep) for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; }
     d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh;
     float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
     float *subs[5] = {sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh};
@@ -1846,7 +2029,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     });
     if (pf) prof_stop(ED3DGS_PROF_DEFORM_FORWARD, s);
     if (!check_hip(hipGetLastError(), "deform forward")) return ED3DGS_ERR_HIP;
-    return 0;
+    return keep ? 1 : 0;
 }
 
 int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
@@ -1854,9 +2037,11 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            const float *g_scales, const float *g_rot, const float *g_opacity, const float *g_sh,
                            const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
                            const float *gs_sh, float *const gparams[2], float *g_table, float *g_offsets,
-                           float *g_embedding, char *workspace, size_t workspace_bytes, void *stream)
+                           float *g_embedding, char *workspace, size_t workspace_bytes, int activations_kept,
+                           void *stream)
 {
     if (!validate(cfg, "ed3dgs_deform_backward")) return ED3DGS_ERR_INVALID;
+    if (activations_kept && !can_keep(cfg)) { set_error("ed3dgs_deform_backward: activations_kept set for a configuration that does not keep them"); return ED3DGS_ERR_INVALID; }
     if (cfg->E != 32) { set_error("ed3dgs_deform_backward: gaussian_embedding_dim must be 32"); return ED3DGS_ERR_INVALID; }
     if (!table || !offsets || !g_table || !g_offsets || !workspace) { set_error("ed3dgs_deform_backward: null pointer"); return ED3DGS_ERR_INVALID; }
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && (!params[s] || !gparams[s])) { set_error("ed3dgs_deform_backward: null params"); return ED3DGS_ERR_INVALID; }
@@ -1924,6 +2109,11 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         dispatch_nt(d.NT, [&](auto nt) {
             constexpr int N = decltype(nt)::value;
             if constexpr (N <= 4) {
+                if (piped && activations_kept) {
+                    const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
+                    hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 512)), dim3(256), lds, s, d);
+                    return;
+                }
                 if (piped) {
                     const size_t lds = (size_t)2 * (2 * N + OTMAX) * 1024 * sizeof(float);
                     okp = check_hip(hipFuncSetAttribute((const void *)deform_dgrad_pipe_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size");

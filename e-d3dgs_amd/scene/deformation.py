@@ -15,6 +15,8 @@ import torch.nn as nn
 from ed3dgs_amd import _lib
 
 HEADS = ("pos", "scales", "rotations", "opacity", "rgb")
+# False: the backward re-forms the activations from the inputs (stateless C-ABI backward; less memory, more MFMA work)
+KEEP_ACTIVATIONS = True
 
 
 def _ptr(t):
@@ -30,7 +32,7 @@ class _DeformFn(torch.autograd.Function):
     parameter blocks, Gaussian embedding, and the five base tensors."""
 
     @staticmethod
-    def forward(ctx, cfgd, want_sub, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh):
+    def forward(ctx, cfgd, want_sub, keep, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh):
         L = _lib.lib()
         cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
         cfg.use_stage[0], cfg.use_stage[1] = cfgd["use_stage"]
@@ -42,15 +44,18 @@ class _DeformFn(torch.autograd.Function):
         table_, offsets_, fc, ff, emb_, xyz_, sc_, rot_, op_, sh_ = ins
         outs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_, sh_)]
         subs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_, sh_)] if want_sub else [None] * 5
-        ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(0))
+        # training: the forward keeps the hidden activations in the backward's workspace (as autograd does for the
+        # reference's Linear/ReLU modules); inference: small workspace, nothing kept
+        ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1 if keep else 0))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
         rc = L.ed3dgs_deform_forward(
             C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
             _ptr(sh_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            C.c_int(1 if keep else 0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
+        ctx.kept_ws = ws if rc == 1 else None
         ctx.cfgd = cfgd
         ctx.want_sub = want_sub
         ctx.save_for_backward(table_, offsets_, fc, ff, emb_)
@@ -76,13 +81,15 @@ class _DeformFn(torch.autograd.Function):
         g_off = torch.empty_like(offsets_)
         g_emb = torch.empty_like(emb_)
         ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        kept = ctx.kept_ws is not None
+        ws = ctx.kept_ws if kept else torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ctx.kept_ws = None
         params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
         gparams = (C.c_void_p * 2)(gfc.data_ptr() if cfgd["use_stage"][0] else None, gff.data_ptr() if cfgd["use_stage"][1] else None)
         rc = L.ed3dgs_deform_backward(
             C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), *[_ptr(g) for g in g_out],
             *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(ws),
-            C.c_size_t(ws_bytes), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         if not cfgd["use_stage"][0]:
@@ -95,7 +102,7 @@ class _DeformFn(torch.autograd.Function):
             g = a if b is None else (b if a is None else a + b)
             base.append(None if g is None else g.reshape(ctx.shapes[5 + i]))
         sh = ctx.shapes
-        return (None, None, g_table.reshape(sh[0]), g_off.reshape(sh[1]), gfc.reshape(sh[2]), gff.reshape(sh[3]),
+        return (None, None, None, g_table.reshape(sh[0]), g_off.reshape(sh[1]), gfc.reshape(sh[2]), gff.reshape(sh[3]),
                 g_emb.reshape(sh[4]), *base)
 
 
@@ -177,8 +184,11 @@ class deform_network(nn.Module):
                     use_stage=(int(not a.no_coarse_deform), int(not a.no_fine_deform)), n_rows=(int(n_c), int(n_f)),
                     no_ds=int(a.no_ds), no_dr=int(a.no_dr), no_do=int(a.no_do), no_dc=int(a.no_dc), coef=coef,
                     coef_c=coef_x, coef_o=coef_x, coef_s=coef_x, time=time, cam_no=-1 if cam_no is None else int(cam_no))
-        res = _DeformFn.apply(cfgd, bool(want_extras), self.weight, self.offsets, self._flat_stage("c"),
-                              self._flat_stage("f"), emb, pts, scales, rotations, opacity, sh_coefs)
+        args = (self.weight, self.offsets, self._flat_stage("c"), self._flat_stage("f"), emb, pts, scales, rotations,
+                opacity, sh_coefs)
+        # decided here: inside autograd.Function.forward grad mode is off
+        keep = KEEP_ACTIVATIONS and torch.is_grad_enabled() and any(t.requires_grad for t in args)
+        res = _DeformFn.apply(cfgd, bool(want_extras), bool(keep), *args)
         final = res[:5]
         sub = res[5:10] if want_extras else orig
         return final[0], final[1], final[2], final[3], final[4], (tuple(sub), orig)

@@ -189,16 +189,22 @@ size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backw
  * Forward.  table[max_embeddings][TD], offsets[num_offsets], params[2] (coarse, fine; NULL if the stage is off),
  * embedding[P][E], base tensors xyz[P,3], scales[P,3], rot[P,4], opacity[P], sh[P,n_sh,3].
  * out_*: values after both stages; sub_*: values after the coarse stage (extras[0], :139-141), may be NULL.
+ * keep_activations != 0 (training): the hidden activations (relu(hid), relu(z_k); 3 KB per Gaussian and stage) are
+ * written into the workspace for ed3dgs_deform_backward, as autograd keeps them for the reference's Linear/ReLU
+ * modules; the workspace must then have ed3dgs_deform_workspace_bytes(cfg, 1) bytes and be passed on to the backward
+ * untouched.  Returns 1 if the activations were kept, 0 if not (not requested, or a configuration whose backward
+ * re-forms them: pass that value as activations_kept), < 0 on error.
  */
 int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
                           const float *const params[2], const float *embedding, const float *xyz,
                           const float *scales, const float *rot, const float *opacity, const float *sh,
                           float *out_xyz, float *out_scales, float *out_rot, float *out_opacity, float *out_sh,
                           float *sub_xyz, float *sub_scales, float *sub_rot, float *sub_opacity, float *sub_sh,
-                          char *workspace, size_t workspace_bytes, void *stream);
+                          char *workspace, size_t workspace_bytes, int keep_activations, void *stream);
 
 /*
- * Backward (stateless: recomputes the forward activations).  g_* = dL/d(out_*), gs_* = dL/d(sub_*); NULL = zero.
+ * Backward.  activations_kept == 0: stateless, re-forms the forward activations; != 0: `workspace` is the one the
+ * forward of the same inputs filled with keep_activations.  g_* = dL/d(out_*), gs_* = dL/d(sub_*); NULL = zero.
  * Every output is fully written: gparams[2] (packed like params), g_table[max_embeddings][TD],
  * g_offsets[num_offsets], g_embedding[P][E].  Gradients w.r.t. the base tensors are g_* + gs_* (identity paths)
  * and are left to the caller.
@@ -210,7 +216,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
                            const float *gs_sh,
                            float *const gparams[2], float *g_table, float *g_offsets, float *g_embedding,
-                           char *workspace, size_t workspace_bytes, void *stream);
+                           char *workspace, size_t workspace_bytes, int activations_kept, void *stream);
 
 #ifdef __cplusplus
 }

@@ -96,12 +96,16 @@ def test_golden_values_and_grads(path):
         assert v <= TOL, (k, v)
 
 
-@pytest.mark.parametrize("P,W", [(5000, 128), (777, 64)])
-def test_against_torch_restatement(P, W):
+@pytest.mark.parametrize("P,W,keep", [(5000, 128, True), (5000, 128, False), (777, 64, True)])
+def test_against_torch_restatement(P, W, keep, monkeypatch):
+    """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
+    keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
     _need_gpu()
     from oracle import deformation_ref as R
     from oracle import deformation_torch as T
+    import scene.deformation as SD
     from scene.deformation import deform_network
+    monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", keep)
     a = R.Args(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000)
     torch.manual_seed(5)
     net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
@@ -120,9 +124,9 @@ def test_against_torch_restatement(P, W):
                          t, None, it, 30, 30, margin_out=mg)
     # Gaussians sitting on a ReLU kink (|pre-activation| within fp32 rounding of 0) have a discontinuous gradient:
     # they are taken out of the loss (both paths), so every compared gradient is well-conditioned.
-    keep = (mg[0] > 1e-6).float()
-    assert keep.mean() > 0.9
-    ws = [mk(*x.shape) * keep.reshape(-1, *([1] * (x.dim() - 1))) for x in list(fin) + list(sub)]
+    off_kink = (mg[0] > 1e-6).float()
+    assert off_kink.mean() > 0.9
+    ws = [mk(*x.shape) * off_kink.reshape(-1, *([1] * (x.dim() - 1))) for x in list(fin) + list(sub)]
     loss = sum((x * w.double()).sum() for x, w in zip(list(fin) + list(sub), ws))
     loss.backward()
     # HIP
