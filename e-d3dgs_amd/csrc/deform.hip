@@ -1666,7 +1666,8 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
     float bsum2[2] = {0.f, 0.f}, bsum3 = 0.f;
 
     f32x4 zv[4], av[4];
-    float gv[NG], g2v[NG];
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 gv, g2v;   // NG <= 8 staged g_y elements (native vectors: arrays captured by the closures below go to scratch)
     const bool has_g2 = J.G2 != nullptr;
     const int gcount = 32 * nk;
     auto load_regs = [&](int slab) {
@@ -1722,7 +1723,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
 #pragma unroll
             for (int kk = 0; kk < KS3; kk++) {
                 const float wv = WIDE ? w3s[(2 * kk + h) * HJ_W + (2 * pmi + t) * 32 + c] : w3f[t][WIDE ? 0 : kk];
-                if (2 * kk < nk) d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);  // rows past nk: zeros
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -1732,7 +1733,8 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             }
         }
         // dW2 patch: k-step kk multiplies Gaussian rows f(kk, h); dW3 tile(s): rows 2kk + h
-#pragma unroll
+        constexpr int UNR = WIDE ? 4 : 16;   // the wide instantiation is at the register limit: fewer operand reads in flight
+#pragma unroll UNR
         for (int kk = 0; kk < 16; kk++) {
             const int rowf = (kk & 3) + 8 * (kk >> 2) + 4 * h;
             const float b0 = as[rowf * HJ_W + (2 * pni) * 32 + c], b1 = as[rowf * HJ_W + (2 * pni + 1) * 32 + c];
@@ -1781,6 +1783,8 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
     if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
+// two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
+template <bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_kernel(HeadWgradArgs a)
 {
     extern __shared__ float hj_lds[];
@@ -1788,8 +1792,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
     const HeadJob &J = a.job[jb];
     const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
-    if (J.nk > 4) head_wgrad_body<true>(J, a.P, split, nsplit, hj_lds);
-    else head_wgrad_body<false>(J, a.P, split, nsplit, hj_lds);
+    head_wgrad_body<WIDE>(J, a.P, split, nsplit, hj_lds);
 }
 
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
@@ -2199,25 +2202,28 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         wa.blk_begin[wa.njobs] = nblk;
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3(nblk), dim3(256), wg_lds, s, wa);
     }
-    if (!hjobs.empty()) {
-        // blocks per job proportional to its MFMA work per slab (g_z tiles + dW2 patch + dW3 tiles), ~2 blocks per CU
+    // narrow heads and the wide head are separate launches (separate register allocations); each launch spreads its
+    // jobs over ~2 blocks per CU
+    for (int wide = 0; wide < 2; wide++) {
         HeadWgradArgs ha;
         std::memset(&ha, 0, sizeof ha);
         ha.P = cfg->P;
-        ha.njobs = (int)hjobs.size();
-        int wsum = 0;
-        std::vector<int> wgt(ha.njobs);
-        for (int q = 0; q < ha.njobs; q++) { wgt[q] = hjobs[q].nk > 4 ? 144 : 84; wsum += wgt[q]; }
+        for (const HeadJob &J : hjobs)
+            if ((J.nk > 4) == (wide != 0)) ha.job[ha.njobs++] = J;
+        if (!ha.njobs) continue;
         int nblk = 0;
         for (int q = 0; q < ha.njobs; q++) {
-            ha.job[q] = hjobs[q];
             ha.blk_begin[q] = nblk;
-            nblk += std::max(1, std::min((cfg->P + 127) / 128, 512 * wgt[q] / wsum));
+            nblk += std::max(1, std::min((cfg->P + 127) / 128, 512 / ha.njobs));
         }
         ha.blk_begin[ha.njobs] = nblk;
-        const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + 48 * HJ_W) * sizeof(float);  // z, a, g_y slabs + W3
-        if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
-        hipLaunchKernelGGL(deform_head_wgrad_kernel, dim3(nblk), dim3(256), lds, s, ha);
+        const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + (wide ? 48 * HJ_W : 0)) * sizeof(float);  // z, a, g_y slabs (+ W3)
+        if (wide) {
+            if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
+            hipLaunchKernelGGL(deform_head_wgrad_kernel<true>, dim3(nblk), dim3(256), lds, s, ha);
+        } else {
+            hipLaunchKernelGGL(deform_head_wgrad_kernel<false>, dim3(nblk), dim3(256), lds, s, ha);
+        }
     }
     if (pw) prof_stop(ED3DGS_PROF_DEFORM_WGRAD, s);
     if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
