@@ -686,6 +686,24 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
         pipe_n++;                                                                                  \
     } while (0)
 
+// Bias handling in the LDS-pipelined kernels: the bias is fetched into registers when a tile starts and ADDED AFTER the
+// tile's MFMAs.  Seeding the accumulator with it would put a global load in front of the first MFMA, and its
+// s_waitcnt vmcnt(0) would also wait for the weight chunk prefetched just before (loads retire in order).
+__device__ __forceinline__ f32x16 zero_acc()
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    return acc;
+}
+__device__ __forceinline__ void load_bias4(f32x4 (&b)[4], const float *__restrict__ bias, int tile, int h)
+{
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(bias + tile * 32 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; q++) b[q] = p[2 * q];
+    __builtin_amdgcn_sched_barrier(0);   // issue here: the scheduler otherwise sinks the loads behind the tile's MFMAs
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_forward_pipe_kernel(DeformDev d)
 {
@@ -728,10 +746,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const float *wb = PIPE_CUR();
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
-                        f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
-                        acc = gemm_tile_lds<1>(wb + nt * 1024, eb, acc, lane);
+                        f32x4 bv[4];
+                        load_bias4(bv, fr + d.fl.HB, nt, h);
+                        const f32x16 acc = gemm_tile_lds<1>(wb + nt * 1024, eb, zero_acc(), lane);
 #pragma unroll
-                        for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r], 0.f);
+                        for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                         if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
                     }
                     PIPE_ADVANCE();
@@ -740,20 +759,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (!d.enabled[k]) continue;
                     f32x16 y[OTMAX];
 #pragma unroll
-                    for (int ot = 0; ot < OTMAX; ot++) y[ot] = bias_acc(fr + d.fl.B3 + (size_t)k * OTMAX * 32, ot, h);
+                    for (int ot = 0; ot < OTMAX; ot++) y[ot] = zero_acc();
                     const int nout = d.ot[k];
 #pragma unroll 1
                     for (int nt = 0; nt < NT; nt++) {
                         const float *wb = PIPE_CUR();
-                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-                        acc = gemm_tile_lds<NT>(wb, a, acc, lane);
+                        f32x4 bv[4];
+                        load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                        const f32x16 acc = gemm_tile_lds<NT>(wb, a, zero_acc(), lane);
                         float z[1][16];
 #pragma unroll
-                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                         if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                         y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
                         if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
                         PIPE_ADVANCE();
+                    }
+                    {   // head output bias, after the contraction (see load_bias4)
+                        const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++) {
+                            if (ot < nout) {
+                                f32x4 bv[4];
+                                load_bias4(bv, b3, ot, h);
+#pragma unroll
+                                for (int r = 0; r < 16; r++) y[ot][r] += bv[r >> 2][r & 3];
+                            }
+                        }
                     }
                     const float hc = d.hc[k];
                     if (k == 0) { if (h == 0) { cx[0] += y[0][0] * hc; cx[1] += y[0][1] * hc; cx[2] += y[0][2] * hc; } }
@@ -823,10 +855,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float *wb = PIPE_CUR();
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
-                    acc = gemm_tile_lds<1>(wb + nt * 1024, eb, acc, lane);
+                    f32x4 bv[4];
+                    load_bias4(bv, fr + d.fl.HB, nt, h);
+                    const f32x16 acc = gemm_tile_lds<1>(wb + nt * 1024, eb, zero_acc(), lane);
 #pragma unroll
-                    for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r], 0.f);
+                    for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                     if (gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
                 }
                 PIPE_ADVANCE();
@@ -872,10 +905,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const float *wb = PIPE_CUR();
                     float z[1][16];
                     {
-                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-                        acc = gemm_tile_lds<NT>(wb, a, acc, lane);
+                        f32x4 bv[4];
+                        load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                        const f32x16 acc = gemm_tile_lds<NT>(wb, a, zero_acc(), lane);
 #pragma unroll
-                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
+                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                     }
                     if (gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                     f32x16 acc;
