@@ -97,6 +97,7 @@ struct DeformDev {
     const float *g[5], *gs[5];
     float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
     float *g_emb;
+    int full_rounds, rem_units, tail_split;  // forward block schedule (see deform_forward_pipe_kernel)
     int keep;      // forward writes a = relu(hid) and relu(z_k) for the backward (activations kept instead of re-formed)
     int store_gz;  // dgrad writes g_z (only the generic wgrad path reads it back)
     int ablate;  // diagnostic builds only: bit mask of phases to skip (timing experiments; results are then wrong)
@@ -625,7 +626,11 @@ __device__ __forceinline__ f32x16 gemm_tile_lds(const float *wl, const float (&x
 template <int NT, bool BWD>
 struct ChunkSeq {
     int s, k, nt;  // k = -1: trunk chunk, k = NHEAD: transposed trunk chunk (BWD)
-    __device__ __forceinline__ void init(const DeformDev &d) { s = d.use_stage[0] ? 0 : 1; k = -1; nt = 0; }
+    int full_left, tail_k;   // block iterations still to walk with every head; after them only head tail_k (tail unit)
+    __device__ __forceinline__ void init(const DeformDev &d, int full_iters = 1 << 30, int tail_head = -1)
+    {
+        s = d.use_stage[0] ? 0 : 1; k = -1; nt = 0; full_left = full_iters; tail_k = tail_head;
+    }
     __device__ __forceinline__ const float *next(const DeformDev &d)
     {
         const int n_chunks = 1 + NHEAD * NT + (BWD ? 1 : 0);
@@ -636,10 +641,11 @@ struct ChunkSeq {
         if (k >= 0 && k < NHEAD && nt + 1 < NT) { nt++; return p; }
         nt = 0;
         int kn = (k >= NHEAD) ? NHEAD + 1 : k + 1;
-        while (kn < NHEAD && !d.enabled[kn]) kn++;
+        while (kn < NHEAD && !(d.enabled[kn] && (full_left > 0 || kn == tail_k))) kn++;
         if (kn < NHEAD) { k = kn; return p; }
         if (BWD && kn == NHEAD) { k = NHEAD; return p; }
         k = -1;  // next stage (or wrap to the first used stage = next block iteration)
+        if (s == (d.use_stage[1] ? 1 : 0)) full_left--;
         s = (s == 0 && d.use_stage[1]) ? 1 : (d.use_stage[0] ? 0 : 1);
         return p;
     }
@@ -670,9 +676,9 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
 #define PIPE_LOAD() stage_load<PIPE_NF4>(pipe_st, reinterpret_cast<const f32x4 *>(pipe_seq.next(d)), tid)
 #define PIPE_COMMIT(buf_) stage_store<PIPE_NF4>(pipe_st, reinterpret_cast<f32x4 *>(wl + (buf_) * PIPE_CHF), tid)
 #define PIPE_CUR() (wl + (pipe_n & 1) * PIPE_CHF)
-#define PIPE_START(total_)                                                                         \
+#define PIPE_START(total_, ...)                                                                    \
     do {                                                                                           \
-        pipe_seq.init(d); pipe_n = 0; pipe_total = (total_);                                       \
+        pipe_seq.init(d, ##__VA_ARGS__); pipe_n = 0; pipe_total = (total_);                        \
         if (pipe_total > 0) { PIPE_LOAD(); PIPE_COMMIT(0); }                                       \
         __syncthreads();                                                                           \
         if (pipe_total > 1) PIPE_LOAD();                                                           \
@@ -714,11 +720,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int shw = 3 * d.n_sh;
     int n_en = 0;
     for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k] ? 1 : 0;
-    const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (1 + n_en * NT);
-    const int my_iters = (n_bi > (int)blockIdx.x) ? (n_bi - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_st = d.use_stage[0] + d.use_stage[1];
+    const int per_iter = n_st * (1 + n_en * NT);
+    // Block schedule.  A block iteration carries 128 Gaussians through everything and the grid is one resident round
+    // (2 blocks per CU), so ceil(n_bi / grid) iterations would leave most of the chip idle during a nearly empty last
+    // round.  When the remainder is small the host sets tail_split: the leftover groups are dealt out as (group, head)
+    // TAIL UNITS -- a block walks the trunk and ONE head of its group (both stages) and writes only that head's tensors.
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
+    const bool has_tail = d.tail_split && b < d.rem_units * n_en;
+    int tail_k = -1;
+    if (has_tail) { int e = b % n_en; for (int k = 0; k < NHEAD; k++) if (d.enabled[k] && e-- == 0) tail_k = k; }
+    const int tail_bi = d.full_rounds * G + (n_en ? b / n_en : 0);
+    (void)n_bi;
     ED3_CHUNK_PIPE(NT, false)
-    PIPE_START(my_iters * per_iter);
-    for (int bi = blockIdx.x; bi < n_bi; bi += gridDim.x) {
+    PIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
+    for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
+        const int bi = (it < my_full) ? b + it * G : tail_bi;
+        const int konly = (it < my_full) ? -1 : tail_k;
         const int g_raw = bi * 128 + wave * 32 + (lane & 31);
         const bool gvalid = g_raw < d.P;
         const int g = gvalid ? g_raw : d.P - 1;
@@ -756,7 +775,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     PIPE_ADVANCE();
                 }
                 for (int k = 0; k < NHEAD; k++) {
-                    if (!d.enabled[k]) continue;
+                    if (!d.enabled[k] || (konly >= 0 && k != konly)) continue;
                     f32x16 y[OTMAX];
 #pragma unroll
                     for (int ot = 0; ot < OTMAX; ot++) y[ot] = zero_acc();
@@ -801,17 +820,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             float *const *dst = (s == 0) ? d.sub : d.out;
-            if (gvalid && dst[0]) {
+            if (gvalid && dst[0]) {   // a tail unit owns one head's tensors (a disabled head's pass-through goes with head 0)
+                const bool w0 = konly <= 0, w1 = konly < 0 || konly == 1 || (konly == 0 && !d.enabled[1]);
+                const bool w2 = konly < 0 || konly == 2 || (konly == 0 && !d.enabled[2]);
+                const bool w3 = konly < 0 || konly == 3 || (konly == 0 && !d.enabled[3]);
+                const bool w4 = konly < 0 || konly == 4 || (konly == 0 && !d.enabled[4]);
                 if (h == 0) {
 #pragma unroll
-                    for (int i = 0; i < 3; i++) { dst[0][(size_t)g * 3 + i] = cx[i]; dst[1][(size_t)g * 3 + i] = cs[i]; }
-                    *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
-                    dst[3][g] = co;
+                    for (int i = 0; i < 3; i++) {
+                        if (w0) dst[0][(size_t)g * 3 + i] = cx[i];
+                        if (w1) dst[1][(size_t)g * 3 + i] = cs[i];
+                    }
+                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    if (w3) dst[3][g] = co;
                 }
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) {
                     const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
-                    if (feat < shw)
+                    if (w4 && feat < shw)
                         *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
                             make_float4(csh[4 * cc], csh[4 * cc + 1], csh[4 * cc + 2], csh[4 * cc + 3]);
                 }
@@ -2058,7 +2084,12 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         if constexpr (N <= 4) {
             if (piped) {  // weights shared through LDS by the block's four waves
                 const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
-                hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 512)), dim3(256), lds, s, d);
+                const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
+                int n_en = 0;
+                for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k];
+                d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
+                d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G && !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
+                hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(G), dim3(256), lds, s, d);
                 return;
             }
         }
