@@ -993,9 +993,12 @@ struct ChunkSeqKept {
     int s, e, nt;   // e = index into the enabled heads; e == n_en: transposed trunk chunk
     int n_en;
     uint32_t en_pack;   // enabled head ids, 4 bits each (a runtime-indexed array would live in scratch)
-    __device__ __forceinline__ void init(const DeformDev &d)
+    int full_left, tail_s;   // block iterations still to walk with both stages; after them only stage tail_s (tail unit)
+    __device__ __forceinline__ void init(const DeformDev &d, int full_iters = 1 << 30, int tail_stage = -1)
     {
-        s = d.use_stage[0] ? 0 : 1; e = 0; nt = 0; n_en = 0; en_pack = 0;
+        full_left = full_iters; tail_s = tail_stage;
+        s = (full_left > 0 || tail_s < 0) ? (d.use_stage[0] ? 0 : 1) : tail_s;
+        e = 0; nt = 0; n_en = 0; en_pack = 0;
         for (int k = 0; k < NHEAD; k++) if (d.enabled[k]) en_pack |= (uint32_t)k << (4 * n_en++);
     }
     __device__ __forceinline__ const float *next(const DeformDev &d)
@@ -1008,7 +1011,11 @@ struct ChunkSeqKept {
         nt = 0;
         if (e < n_en) { e++; return p; }
         e = 0;
-        s = (s == 0 && d.use_stage[1]) ? 1 : (d.use_stage[0] ? 0 : 1);
+        if (full_left > 0) {
+            const bool last = (s == (d.use_stage[1] ? 1 : 0));
+            s = (s == 0 && d.use_stage[1]) ? 1 : (d.use_stage[0] ? 0 : 1);
+            if (last && --full_left == 0 && tail_s >= 0) s = tail_s;
+        }
         return p;
     }
 };
@@ -1040,11 +1047,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int k = 0; k < NHEAD; k++) if (d.enabled[k]) en_pack |= (uint32_t)k << (4 * n_en++);
 #define EN_K(e_) ((int)(en_pack >> (4 * (e_)) & 15u))
     const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (n_en * NT + 1);
-    const int my_iters = (n_bi > (int)blockIdx.x) ? (n_bi - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // block schedule as in deform_forward_pipe_kernel; here a TAIL UNIT is (group, stage): the two stages of a group
+    // are independent up to dL/d embedding, which the two units add atomically into zeroed rows (two addends: the
+    // result does not depend on their order)
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
+    const bool has_tail = d.tail_split && b < d.rem_units * 2;
+    const int tail_s = has_tail ? (b & 1) : -1;
+    const int tail_bi = d.full_rounds * G + (b >> 1);
+    (void)n_bi;
     const size_t PW = (size_t)d.P * d.W;
     ED3_CHUNK_PIPE_KEPT(NT)
-    PIPE_START(my_iters * per_iter);
-    for (int bi = blockIdx.x; bi < n_bi; bi += gridDim.x) {
+    PIPE_START(my_full * per_iter + (has_tail ? n_en * NT + 1 : 0), my_full, tail_s);
+    for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
+        const int bi = (it < my_full) ? b + it * G : tail_bi;
+        const int sonly = (it < my_full) ? -1 : tail_s;
         const int g_raw = bi * 128 + wave * 32 + (lane & 31);
         const bool gvalid = g_raw < d.P;
         const int g = gvalid ? g_raw : d.P - 1;
@@ -1053,7 +1070,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int r = 0; r < 16; r++) ge[r] = 0.f;
 #pragma unroll 1
         for (int s = 0; s < 2; s++) {
-            if (!d.use_stage[s]) continue;
+            if (!d.use_stage[s] || (sonly >= 0 && s != sonly)) continue;
             const bool add_sub = (s == 0);
             const bool add_out = (s == 1) || both || !d.use_stage[1];
             f32x16 ga[NT];
@@ -1141,10 +1158,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             PIPE_ADVANCE();
         }
         if (gvalid) {
-            float v[16];
+            if (sonly >= 0) {   // tail unit: one of two addends into rows the host zeroed
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = ge[r];
-            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+                for (int r = 0; r < 16; r++) atomicAdd(d.g_emb + (size_t)g * d.E + (r & 3) + 8 * (r >> 2) + 4 * h, ge[r]);
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = ge[r];
+                store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+            }
         }
     }
 }
@@ -2179,7 +2201,16 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
             if constexpr (N <= 4) {
                 if (piped && activations_kept) {
                     const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
-                    hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 512)), dim3(256), lds, s, d);
+                    const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
+                    d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
+                    d.tail_split = (d.rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && d.rem_units * 2 <= G &&
+                                    !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
+                    if (d.tail_split) {   // the tail groups' rows of dL/d embedding are accumulated by two units each
+                        const size_t r0 = (size_t)d.full_rounds * G * 128;
+                        okp = check_hip(hipMemsetAsync(g_embedding + r0 * cfg->E, 0, ((size_t)cfg->P - r0) * cfg->E * sizeof(float), s), "memset g_emb tail");
+                        if (!okp) return;
+                    }
+                    hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(G), dim3(256), lds, s, d);
                     return;
                 }
                 if (piped) {
