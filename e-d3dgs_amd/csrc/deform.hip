@@ -1739,6 +1739,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             }
     }
     f32x16 acc[2][2], acc3[MT3];
+    f32x4 acc3n = {0.f, 0.f, 0.f, 0.f};   // narrow heads: dW3 on the 16-block 4x4x1 MFMA (4 outputs x 4 features per block)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
@@ -1802,7 +1803,8 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = 0.f;
-#pragma unroll
+            constexpr int UNG = WIDE ? 4 : KS3;   // the 24-step product fully unrolled pushes the wide body into scratch
+#pragma unroll UNG
             for (int kk = 0; kk < KS3; kk++) {
                 const float wv = WIDE ? w3s[(2 * kk + h) * HJ_W + (2 * pmi + t) * 32 + c] : w3f[t][WIDE ? 0 : kk];
                 d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);  // rows past nk: zeros
@@ -1826,9 +1828,15 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[1][kk], b1, acc[1][1], 0, 0, 0);
             const int row = 2 * kk + h;
             const float zb = zs[row * HJ_W + wave * 32 + c];
+            if constexpr (WIDE) {
 #pragma unroll
-            for (int t = 0; t < MT3; t++)
-                acc3[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[row * LDG + t * 32 + c], zb, acc3[t], 0, 0, 0);
+                for (int t = 0; t < MT3; t++)
+                    acc3[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[row * LDG + t * 32 + c], zb, acc3[t], 0, 0, 0);
+            } else {
+                // block b = lane / 4 = (row parity h, feature group c / 4): D_b[i][j] += g_y[row][i] * relu(z)[row][4 (c/4) + j];
+                // a 32x32x2 tile would spend 64 cycles on 4 useful rows, this spends 8
+                acc3n = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[row * LDG + (lane & 3)], zb, acc3n, 0, 0, 0);
+            }
         }
         if (tid < nk) {
 #pragma unroll 8
@@ -1848,13 +1856,21 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                 const int mi = (2 * pmi + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 atomicAdd(J.dW2 + (size_t)mi * HJ_W + (2 * pni + u) * 32 + c, acc[t][u][r]);
             }
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int t = 0; t < MT3; t++)
+        for (int t = 0; t < MT3; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, acc3[t][r]);
+            for (int r = 0; r < 16; r++) {
+                const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, acc3[t][r]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // the two row-parity blocks of a feature group sit 32 lanes apart
+            const float v = acc3n[i] + __shfl_xor(acc3n[i], 32);
+            if (h == 0 && i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, v);
         }
+    }
     if (pni == 0) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
