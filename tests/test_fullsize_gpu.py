@@ -33,6 +33,12 @@ def test_c2_forward_and_backward_parity_100k_1080p():
     print("C2 fwd", errs, "excluded", frac, "R", fw["num_rendered"])
     grads = S.make_upstream_grads(1080, 1920)
     grads["coord"].zero_(); grads["mcoord"].zero_()
+    # pixels with a blend decision within rounding of its threshold get no upstream gradient on either side (a pair
+    # taken by one implementation and skipped by the other is a 1/255-sized term; see test_backward_ragged_sizes)
+    goodf = torch.from_numpy(good.astype(np.float32))
+    assert goodf.mean() > 0.99
+    for k in grads:
+        grads[k] = grads[k] * goodf
     fw_hip = dict(fw)
     fw_hip.update(alpha=out[4].cpu().numpy(), normal=out[6].cpu().numpy(), n_contrib=sv["n_contrib"],
                   accum_coord=sv["accum_coord"], accum_depth=sv["accum_depth"], normal_length=sv["normal_length"])
@@ -48,11 +54,8 @@ def test_c2_forward_and_backward_parity_100k_1080p():
     names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
     gerr = {n: _grad_err(t.cpu().numpy().reshape(bw[n].shape), bw[n]) for n, t in zip(names, res)}
     print("C2 bwd (kernel level)", gerr)
-    # looser than TOL_GRAD (5e-5 at C1): the oracle re-evaluates every alpha with libm expf while the state it is fed
-    # (alpha_out, i.e. T_final) was accumulated with the HIP kernel's exp2; along the T /= (1 - alpha) chain a 1e-7
-    # difference in alpha is amplified by 1/(1 - alpha) (up to 100x), and at 100k Gaussians the stacks are deep.
     for n, v in gerr.items():
-        assert v <= 5e-4, (n, v)
+        assert v <= TOL_GRAD, (n, v)
 
 
 def test_c3_properties_200k_deform_on():
