@@ -147,12 +147,23 @@ class deform_network(nn.Module):
 
     # ---- helpers of the fused path ----
     def _flat_stage(self, s):
+        """The stage's parameters packed as include/ed3dgs.h lays them out.  With autograd on this is a `cat` node (the
+        packed gradient flows back to the modules' parameters); without it (rendering) the packed copy is reused until
+        a parameter changes (torch's per-tensor version counters and storage pointers are the key)."""
         mods = [getattr(self, f"feature_out_{s}")[0]]
-        parts = [mods[0].weight.reshape(-1), mods[0].bias]
+        parts = [mods[0].weight, mods[0].bias]
         for h in HEADS:
             seq = getattr(self, f"{h}_deform_{s}")
-            parts += [seq[1].weight.reshape(-1), seq[1].bias, seq[3].weight.reshape(-1), seq[3].bias]
-        return torch.cat(parts)
+            parts += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
+        if torch.is_grad_enabled():
+            return torch.cat([p.reshape(-1) for p in parts])
+        key = tuple((p.data_ptr(), p._version) for p in parts)
+        cache = self.__dict__.setdefault("_flat_cache", {})
+        hit = cache.get(s)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([p.detach().reshape(-1) for p in parts]))
+            cache[s] = hit
+        return hit[1]
 
     def _row_counts(self, it, num_down_emb_c, num_down_emb_f):
         """query_time (:72-80)"""
