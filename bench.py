@@ -292,8 +292,10 @@ def main():
                 "note": "dominant kernel of the step by time; fp32 operands on v_mfma_f32_32x32x2f32 (dense f32 MFMA peak "
                         "157.3 TFLOP/s); algorithmic flops = 2 * %d MAC per Gaussian" % macs}
         if dom == 4:
-            roof["note"] += ("; the head kernel also re-forms g_z = (g_y W3) * (z > 0) per slab and pads the narrow heads' "
-                             "dW3 to 32 rows, so it executes ~1.3x this count")
+            roof["note"] += ("; one weight-gradient pass = three back-to-back launches timed by one event pair "
+                             "(deform_wgrad_kernel, deform_head_wgrad_kernel<true>, deform_head_wgrad_kernel<false>: "
+                             "add their rocprofv3 averages); the head kernels also re-form g_z = (g_y W3) * (z > 0) per "
+                             "slab, so they execute ~1.15x this count")
     else:
         roof = roof_k7
     res = {
