@@ -776,42 +776,71 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
                 for (int k = 0; k < NHEAD; k++) {
                     if (!d.enabled[k] || (konly >= 0 && k != konly)) continue;
-                    f32x16 y[OTMAX];
-#pragma unroll
-                    for (int ot = 0; ot < OTMAX; ot++) y[ot] = zero_acc();
-                    const int nout = d.ot[k];
+                    const float hc = d.hc[k];
+                    if (k < 4) {
+                        // narrow heads (3 / 3 / 4 / 1 outputs): the output contraction runs on the 16-block 4x4x1 MFMA --
+                        // block b = lane / 4 takes Gaussians 4 (b & 7) .. +3 and the feature this lane half holds in z at
+                        // k-slot kk, so B is z as it stands, and A (W3[i = lane & 3][that feature]) is a 4-address gather
+                        // from the head's ordinary 32x32x2 fragment.  8 cycles per step instead of 64 on a tile with 4
+                        // useful rows.
+                        f32x4 yn = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-                    for (int nt = 0; nt < NT; nt++) {
-                        const float *wb = PIPE_CUR();
-                        f32x4 bv[4];
-                        load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-                        const f32x16 acc = gemm_tile_lds<NT>(wb, a, zero_acc(), lane);
-                        float z[1][16];
+                        for (int nt = 0; nt < NT; nt++) {
+                            const float *wb = PIPE_CUR();
+                            f32x4 bv[4];
+                            load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                            const f32x16 acc = gemm_tile_lds<NT>(wb, a, zero_acc(), lane);
+                            float z[1][16];
 #pragma unroll
-                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
-                        if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
-                        y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
-                        if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
-                        PIPE_ADVANCE();
-                    }
-                    {   // head output bias, after the contraction (see load_bias4)
+                            for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                            if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            const float *f3 = wb + NT * 1024 + 32 * h + (lane & 3);
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++)
+                                yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
+                            PIPE_ADVANCE();
+                        }
                         const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+                        float yo[4];
 #pragma unroll
-                        for (int ot = 0; ot < OTMAX; ot++) {
-                            if (ot < nout) {
-                                f32x4 bv[4];
-                                load_bias4(bv, b3, ot, h);
+                        for (int i = 0; i < 4; i++) yo[i] = (yn[i] + __shfl_xor(yn[i], 32) + b3[i]) * hc;  // the two feature halves
+                        if (h == 0) {
+                            if (k == 0) { cx[0] += yo[0]; cx[1] += yo[1]; cx[2] += yo[2]; }
+                            else if (k == 1) { cs[0] += yo[0]; cs[1] += yo[1]; cs[2] += yo[2]; }
+                            else if (k == 2) { cr[0] += yo[0]; cr[1] += yo[1]; cr[2] += yo[2]; cr[3] += yo[3]; }
+                            else co += yo[0];
+                        }
+                    } else {
+                        f32x16 y[OTMAX];
 #pragma unroll
-                                for (int r = 0; r < 16; r++) y[ot][r] += bv[r >> 2][r & 3];
+                        for (int ot = 0; ot < OTMAX; ot++) y[ot] = zero_acc();
+                        const int nout = d.ot[k];
+#pragma unroll 1
+                        for (int nt = 0; nt < NT; nt++) {
+                            const float *wb = PIPE_CUR();
+                            f32x4 bv[4];
+                            load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                            const f32x16 acc = gemm_tile_lds<NT>(wb, a, zero_acc(), lane);
+                            float z[1][16];
+#pragma unroll
+                            for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                            if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
+                            if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
+                            PIPE_ADVANCE();
+                        }
+                        {   // head output bias, after the contraction (see load_bias4)
+                            const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+#pragma unroll
+                            for (int ot = 0; ot < OTMAX; ot++) {
+                                if (ot < nout) {
+                                    f32x4 bv[4];
+                                    load_bias4(bv, b3, ot, h);
+#pragma unroll
+                                    for (int r = 0; r < 16; r++) y[ot][r] += bv[r >> 2][r & 3];
+                                }
                             }
                         }
-                    }
-                    const float hc = d.hc[k];
-                    if (k == 0) { if (h == 0) { cx[0] += y[0][0] * hc; cx[1] += y[0][1] * hc; cx[2] += y[0][2] * hc; } }
-                    else if (k == 1) { if (h == 0) { cs[0] += y[0][0] * hc; cs[1] += y[0][1] * hc; cs[2] += y[0][2] * hc; } }
-                    else if (k == 2) { if (h == 0) { cr[0] += y[0][0] * hc; cr[1] += y[0][1] * hc; cr[2] += y[0][2] * hc; cr[3] += y[0][3] * hc; } }
-                    else if (k == 3) { if (h == 0) co += y[0][0] * hc; }
-                    else {
 #pragma unroll
                         for (int r = 0; r < 16; r++) csh[r] += y[0][r] * hc;
 #pragma unroll
