@@ -1,9 +1,11 @@
 """SynthGaussianModel -- the slice of scene/gaussian_model.py:GaussianModel that render() touches, built from a
-synthetic scene (ed3dgs_amd.synthetic).  Attribute names, activation callables and the 3D-filter formula follow
-scene/gaussian_model.py:37-45, 112-141, 594-603; training bookkeeping (optimizer, densification, PLY I/O) is out of
-this round's hot-path scope."""
+synthetic scene (ed3dgs_amd.synthetic) or from a reference checkpoint (`load_checkpoint`: point_cloud.ply +
+deformation.pth, scene/gaussian_model.py:250-347).  Attribute names, activation callables and the 3D-filter formula
+follow scene/gaussian_model.py:37-45, 112-141, 538-603; training bookkeeping (optimizer, densification) is out of scope."""
+import os
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -91,6 +93,88 @@ class SynthGaussianModel:
     def parameters(self):
         return [self._xyz, self._scaling, self._rotation, self._opacity, self._features_dc, self._features_rest,
                 self._embedding] + list(self._deformation.parameters())
+
+    # ---- the reference's on-disk formats (scene/gaussian_model.py:250-347) ----
+    def save_ply(self, path):
+        """save_ply (:261-283): one `vertex` element, all-float properties in construct_list_of_attributes order."""
+        from . import ply
+        d = lambda t: t.detach().cpu().numpy().astype(np.float32)
+        xyz = d(self._xyz)
+        f_dc = d(self._features_dc.transpose(1, 2).flatten(start_dim=1))
+        f_rest = d(self._features_rest.transpose(1, 2).flatten(start_dim=1))
+        cols = [xyz, np.zeros_like(xyz), f_dc, f_rest, d(self._opacity), d(self._scaling), d(self._rotation),
+                d(self._embedding), d(self.tongue_class), d(self.filter_3D)]
+        names = ply.attribute_names(f_dc.shape[1], f_rest.shape[1], self._scaling.shape[1], self._rotation.shape[1],
+                                    self._embedding.shape[1])
+        flat = np.concatenate(cols, axis=1)
+        assert flat.shape[1] == len(names)
+        elements = np.empty(xyz.shape[0], dtype=[(n, "f4") for n in names])
+        for i, n in enumerate(names):
+            elements[n] = flat[:, i]
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        ply.write_vertices(path, elements)
+
+    def load_ply(self, path, device="cuda"):
+        """load_ply (:295-347): same field handling (missing tongue_class -> zeros; f_rest_* / scale_* / rot_* /
+        embedding_* sorted by their numeric suffix)."""
+        from . import ply
+        v = ply.read_vertices(path)
+        names = v.dtype.names
+        col = lambda n: np.asarray(v[n], np.float32)
+        by_suffix = lambda pre: sorted([n for n in names if n.startswith(pre)], key=lambda x: int(x.split("_")[-1]))
+        xyz = np.stack([col("x"), col("y"), col("z")], axis=1)
+        P = xyz.shape[0]
+        opac = col("opacity")[:, None]
+        tongue = col("tongue_class")[:, None] if "tongue_class" in names else np.zeros_like(opac)
+        filt = col("filter_3D")[:, None]
+        f_dc = np.stack([col("f_dc_0"), col("f_dc_1"), col("f_dc_2")], axis=1)[:, :, None]      # (P, 3, 1)
+        rest = by_suffix("f_rest_")
+        if len(rest) != 3 * (self.max_sh_degree + 1) ** 2 - 3:
+            raise ValueError("load_ply: %d f_rest_* properties do not match max_sh_degree=%d" % (len(rest), self.max_sh_degree))
+        f_rest = np.stack([col(n) for n in rest], axis=1).reshape(P, 3, (self.max_sh_degree + 1) ** 2 - 1)
+        scales = np.stack([col(n) for n in by_suffix("scale_")], axis=1)
+        rots = np.stack([col(n) for n in by_suffix("rot")], axis=1)
+        emb = np.stack([col(n) for n in by_suffix("embedding")], axis=1)
+        p = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float, device=device).contiguous().requires_grad_(True))
+        self._xyz, self._opacity, self._scaling, self._rotation, self._embedding = p(xyz), p(opac), p(scales), p(rots), p(emb)
+        self._features_dc = nn.Parameter(torch.tensor(f_dc, dtype=torch.float, device=device).transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(torch.tensor(f_rest, dtype=torch.float, device=device).transpose(1, 2).contiguous().requires_grad_(True))
+        self.filter_3D = torch.tensor(filt, dtype=torch.float, device=device)
+        self.tongue_class = torch.tensor(tongue, dtype=torch.float, device=device)
+        self.active_sh_degree = self.max_sh_degree
+
+    def save_deformation(self, path):
+        """save_deformation (:258-259)"""
+        os.makedirs(path, exist_ok=True)
+        torch.save(self._deformation.state_dict(), os.path.join(path, "deformation.pth"))
+
+    def load_model(self, path, device="cuda"):
+        """load_model (:250-256); the file is read with weights_only=True (tensors only, nothing is executed)."""
+        sd = torch.load(os.path.join(path, "deformation.pth"), map_location="cpu", weights_only=True)
+        self._deformation.load_state_dict(sd)
+        self._deformation = self._deformation.to(device)
+
+    @torch.no_grad()
+    def compute_3D_filter(self, cameras):
+        """compute_3D_filter (:538-592) on the GPU (csrc/filter3d.hip)."""
+        from .filter3d import compute_3D_filter
+        self.filter_3D = compute_3D_filter(self.get_xyz, cameras)
+
+    @torch.no_grad()
+    def reset_3D_filter(self):
+        """reset_3D_filter (:533-536)"""
+        self.filter_3D = torch.zeros([self.get_xyz.shape[0], 1], device=self.get_xyz.device)
+
+
+def load_checkpoint(model_path, iteration, args=None, sh_degree=3, device="cuda"):
+    """A render-ready model from `<model_path>/point_cloud/iteration_<n>/{point_cloud.ply, deformation.pth}` (the layout
+    scene/__init__.py writes: Scene.save -> save_ply + save_deformation)."""
+    from .synthetic import make_scene
+    d = os.path.join(model_path, "point_cloud", "iteration_%d" % iteration)
+    m = SynthGaussianModel(make_scene(1, sh_degree=sh_degree), args=args, device=device, table_scale=1.0)
+    m.load_ply(os.path.join(d, "point_cloud.ply"), device=device)
+    m.load_model(d, device=device)
+    return m
 
 
 PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)

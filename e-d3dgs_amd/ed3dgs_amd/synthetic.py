@@ -71,6 +71,7 @@ class SynthCamera:
     """The subset of scene/cameras.py:Camera that render() reads."""
 
     def __init__(self, R, T, FoVx, FoVy, width, height, time=0.0, device="cpu"):
+        self.R, self.T = np.asarray(R, np.float64), np.asarray(T, np.float64)   # as scene/cameras.py:Camera keeps them
         self.FoVx, self.FoVy = FoVx, FoVy
         self.image_width, self.image_height = int(width), int(height)
         self.time = float(time)

@@ -137,6 +137,18 @@ int ed3dgs_activations_backward(int P, const float *scales_log, const float *rot
                                 const float *g_opacity, float *g_scales_log, float *g_rot_raw, float *g_opacity_logit,
                                 void *stream);
 
+/*
+ * GaussianModel.compute_3D_filter (scene/gaussian_model.py:538-592): filter_3D[i] = z_min(i) / focal_max * sqrt(0.2),
+ * z_min = smallest camera-space depth over the cameras that see Gaussian i (z > 0.2, projection inside the image
+ * enlarged by 15 % per side); Gaussians no camera sees take the largest z_min of the others.  `cams` is a HOST array
+ * of n_cams x 16 floats: R (3x3 row-major, as Camera.R: xyz_cam = xyz @ R + T), T, focal_x, focal_y, width, height.
+ * xyz [P,3] and filter_3D [P] are device pointers; workspace >= ed3dgs_filter3d_workspace_bytes(P) device bytes.
+ * If no camera sees any Gaussian the result is all zeros (the reference raises on the empty max).
+ */
+size_t ed3dgs_filter3d_workspace_bytes(int P);
+int ed3dgs_compute_3d_filter(int P, const float *xyz, int n_cams, const float *cams, float *filter_3D,
+                             char *workspace, size_t workspace_bytes, void *stream);
+
 /* Measurement aid (bench.py): while enabled, the tile forward (K6) and tile backward (K7) launches are bracketed by
  * hipEvents on the stream they are launched on; ed3dgs_profile_end synchronises those events and returns the summed
  * kernel durations in milliseconds and the launch counts.  Not part of the data path. */
