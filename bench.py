@@ -49,7 +49,7 @@ def build(workload, device):
     return wl, model, cams, grads
 
 
-def make_step(model, cams, grads, wl, device):
+def make_step(model, cams, grads, wl, device, dp_grads=False):
     from ed3dgs_amd import dist as D
     from ed3dgs_amd.model import PIPE
     from gaussian_renderer import render
@@ -71,6 +71,8 @@ def make_step(model, cams, grads, wl, device):
         mse = (pkg["render"].detach() - 0.5).square().mean()
         stats = torch.stack([loss.detach(), -10.0 * torch.log10(mse), torch.ones((), device=device)])
         D.allreduce_sum_(stats)  # the path's one collective (RCCL over xGMI): 12 bytes
+        if dp_grads:             # opt-in: data-parallel training, mean of the ranks' gradients
+            D.allreduce_gradients_(params)
         for p in params:
             p.grad = None
         pkg["viewspace_points"].grad = None
@@ -170,6 +172,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-grads", action="store_true", help="also all-reduce the gradients every step (data-parallel training; not the headline configuration)")
     a = ap.parse_args()
 
     from ed3dgs_amd import dist as D
@@ -185,7 +188,7 @@ def main():
     log("building workload", a.workload)
     wl, model, cams, grads = build(a.workload, device)
     log("built; warm-up")
-    step = make_step(model, cams, grads, wl, device)
+    step = make_step(model, cams, grads, wl, device, dp_grads=a.dp_grads)
     n_items = wl["cams"] * wl["frames"]
     my_items = D.shard_items(max(n_items, world), rank, world)
     item_at = lambda k: my_items[k % len(my_items)] % n_items
@@ -304,7 +307,7 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "gaussians": wl["P"], "resolution": [wl["W"], wl["H"]],
-                   "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step",
+                   "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step" + ("; + bucketed gradient all-reduce (--dp-grads)" if a.dp_grads else ""),
                    "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
         "render_fps": world * a.steps / dt_r,
         "render_fps_note": "forward only, all outputs (coord+depth+normal), torch.no_grad, incl. deformation",

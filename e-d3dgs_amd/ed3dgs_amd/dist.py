@@ -73,3 +73,44 @@ def max_over_ranks(value, device):
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         t = w
     return float(t[0])
+
+
+def allreduce_gradients_(params, bucket_bytes=64 << 20, average=True):
+    """Data-parallel training on top of the frame sharding (the reference is single-GPU, train.py
+    :345-348 steps its optimizer on one rank's gradients): SUM (or mean) the ranks' gradients in place, in flat buckets.
+    xGMI is point-to-point (7 links per GPU), so a ring all-reduce is bound per link: few large buckets (64 MB) keep the
+    links streaming and the launch count low; each bucket's collective is issued asynchronously and the copies back wait
+    on it, so bucket k+1's packing overlaps bucket k's transfer.  Parameters whose .grad is None contribute zeros (a
+    rank whose frame saw nothing of a parameter must still take part in the collective)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    world = dist.get_world_size()
+    params = [p for p in params if p.requires_grad]
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nb = p.numel() * p.element_size()
+        if cur and (cur_bytes + nb > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+            buckets.append(cur); cur, cur_bytes = [], 0
+        cur.append(p); cur_bytes += nb
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+        wire = _on_wire(flat)
+        pending.append((b, flat, wire, dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)))
+    for b, flat, wire, work in pending:
+        work.wait()
+        if wire is not flat:
+            flat.copy_(wire)
+        if average:
+            flat.div_(world)
+        off = 0
+        for p in b:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n

@@ -49,6 +49,44 @@ def test_two_rank_sharding_and_allreduce(tmp_path):
     assert res[0]["n_pairs"] == len(a)                                   # (camera, frame) pairs are distinct
 
 
+GRAD_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.path.join(%(root)r, "e-d3dgs_amd"))
+import torch
+from ed3dgs_amd import dist as D
+rank, world, local = D.init(backend="gloo")
+torch.manual_seed(0)
+ps = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 70000, 3, 1 << 18)] + [torch.nn.Parameter(torch.zeros(4), requires_grad=False)]
+for i, p in enumerate(ps[:4]):
+    p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+if rank == 1:
+    ps[2].grad = None            # a rank without a gradient for a parameter still takes part (zeros)
+D.allreduce_gradients_(ps, bucket_bytes=300_000, average=True)
+out = [float(p.grad[0]) for p in ps[:4]] + [float(p.grad.min()) == float(p.grad.max()) for p in ps[:4]]
+print(json.dumps(dict(rank=rank, out=out, frozen=ps[4].grad is None)))
+'''
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    """SURVEY 8(f) rank 2: bucketed mean of the ranks' gradients (several buckets, a missing gradient, a frozen one)."""
+    script = tmp_path / "gworker.py"
+    script.write_text(GRAD_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    import json
+    res = []
+    for p in procs:
+        o, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        res.append(json.loads(o.strip().splitlines()[-1]))
+    for r in res:
+        # mean over ranks of (rank + 1) * (i + 1): 1.5 (i + 1); parameter 2 had a gradient on rank 0 only: 3 / 2
+        assert r["out"][:4] == [1.5, 3.0, 1.5, 6.0] and all(r["out"][4:]) and r["frozen"]
+
+
 def test_item_mapping_is_bijective():
     sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
     from ed3dgs_amd import dist as D
