@@ -43,6 +43,38 @@ __device__ __forceinline__ float gauss_alpha(float w, float G)
     return fminf(0.99f, w * G);
 }
 
+// Tile-level reject, evaluated by ONE lane per list entry while the chunk is staged: can this Gaussian reach
+// alpha >= 1/255 anywhere in the pixel box [x0, x1] x [y0, y1]?  alpha = min(0.99, w exp(power)) with
+// power(d) = -(0.5 cx dx^2 + cy dx dy + 0.5 cz dy^2), so the question is whether the minimum of the quadratic over
+// the box is <= ln(255 w).  The minimum of a quadratic over a box that does not contain its stationary point lies on
+// an edge, and on an edge it is a clamped 1-D minimisation (cx, cz > 0).  The answer is CONSERVATIVE (a margin covers
+// the rounding of this test and of the per-pixel evaluation; degenerate or non-finite inputs answer yes): entries it
+// rejects are exactly entries the per-pixel tests would reject for all 256 pixels, so skipping them changes no output
+// bit -- the reference's 3-sigma SQUARE binning (CR/auxiliary.h:46-57) puts ~40 % such entries into the lists.
+__device__ __forceinline__ bool tile_may_contribute(float mx, float my, float cx, float cy, float cz, float w,
+                                                    float x0, float y0, float x1, float y1)
+{
+    if (!(cx > 0.f) || !(cz > 0.f) || !(w == w) || !(cy == cy) || !(mx == mx) || !(my == my)) return true;
+    if (!(w > 0.f)) return false;                       // alpha <= 0 < 1/255 everywhere
+    const float lim = __logf(255.0f * w);               // need min Q <= lim
+    if (lim < -1e-3f) return false;                     // w < 1/255: alpha < 1/255 wherever power <= 0 (power > 0 is skipped)
+    const float dxlo = mx - x1, dxhi = mx - x0, dylo = my - y1, dyhi = my - y0;
+    if (dxlo <= 0.f && dxhi >= 0.f && dylo <= 0.f && dyhi >= 0.f) return true;
+    const float ryc = -cy / cz, rxc = -cy / cx;
+    float qmin = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const float xe = e ? dxhi : dxlo;
+        const float ys = fminf(fmaxf(ryc * xe, dylo), dyhi);
+        qmin = fminf(qmin, 0.5f * cx * xe * xe + cy * xe * ys + 0.5f * cz * ys * ys);
+        const float ye = e ? dyhi : dylo;
+        const float xs = fminf(fmaxf(rxc * ye, dxlo), dxhi);
+        qmin = fminf(qmin, 0.5f * cx * xs * xs + cy * xs * ye + 0.5f * cz * ye * ye);
+    }
+    if (!(qmin == qmin)) return true;
+    return qmin <= lim + 1e-3f + 1e-4f * fabsf(lim);
+}
+
 // 4-wide row-segment load/store for the lane's pixels. `vec` = whole segment inside and 16-byte aligned.
 __device__ __forceinline__ void store4(float *__restrict__ plane, size_t pix0, const float v[4], bool vec, int nvalid)
 {

@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
 #pragma unroll
     for (int p = 0; p < 4; p++) fpx[p] = (float)(px0 + p);
     const uint2 range = ranges[tile];
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     // ---- per-pixel state (prologue in scalars, then packed into pixel pairs) ----
     float T[4], V[4];                         // transmittance; suffix sum of w_j * s_j (+ T_final * bg . dL_dpixel)
@@ -224,12 +225,15 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     for (int top = tile_max; top > 0; top -= 64) {
         __syncthreads();
         const int cnt = min(64, top);
+        bool keep = false;
         if (lane < cnt) {
             const uint32_t id = point_list[range.x + (uint32_t)(top - 1 - lane)];
             const float4 *src = rec + (size_t)id * 4;
+            const float4 q0 = src[0], q1 = src[1];
             s_id[lane] = id;
-            s_rec[lane * 4 + 0] = src[0];
-            s_rec[lane * 4 + 1] = src[1];
+            s_rec[lane * 4 + 0] = q0;
+            s_rec[lane * 4 + 1] = q1;
+            keep = tile_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0, tile_x0 + (TILE - 1), tile_y0 + (TILE - 1));
             s_rec[lane * 4 + 2] = src[2];
             if (GEO) s_rec[lane * 4 + 3] = src[3];
             if (COORD) {
@@ -238,7 +242,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             }
         }
         __syncthreads();
-        for (int j = 0; j < cnt; j++) {
+        // entries that cannot reach alpha >= 1/255 anywhere in the tile are never visited (raster_common.h)
+        unsigned long long live = __ballot(keep);
+        while (live) {
+            const int j = __builtin_ctzll(live);
+            live &= live - 1;
             const uint32_t k = (uint32_t)(top - 1 - j);  // 0-based position in the tile list
             const float4 r0 = s_rec[j * 4 + 0];          // x, y, cx, cy
             const float4 r1 = s_rec[j * 4 + 1];          // cz, w, r, g

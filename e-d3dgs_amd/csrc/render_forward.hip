@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     float T[4], C0[4], C1[4], C2[4], TG[4], WT[4];
     float DP[4], MD[4], N0[4], N1[4], N2[4];
@@ -55,11 +56,14 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
         if (__all(done[0] && done[1] && done[2] && done[3])) break;
         __syncthreads();
         const int k = base + lane;
+        bool keep = false;
         if (k < n) {
             const uint32_t id = point_list[range.x + k];
             const float4 *src = rec + (size_t)id * 4;
-            s_rec[lane * 4 + 0] = src[0];
-            s_rec[lane * 4 + 1] = src[1];
+            const float4 q0 = src[0], q1 = src[1];
+            s_rec[lane * 4 + 0] = q0;
+            s_rec[lane * 4 + 1] = q1;
+            keep = tile_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0, tile_x0 + (TILE - 1), tile_y0 + (TILE - 1));
             if (GEO) { s_rec[lane * 4 + 2] = src[2]; s_rec[lane * 4 + 3] = src[3]; }
             else     { s_rec[lane * 4 + 2] = src[2]; }
             if (COORD) {
@@ -68,8 +72,11 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
             }
         }
         __syncthreads();
-        const int cnt = min(64, n - base);
-        for (int j = 0; j < cnt; j++) {
+        // entries that cannot reach alpha >= 1/255 anywhere in the tile are never visited (raster_common.h)
+        unsigned long long live = __ballot(keep);
+        while (live) {
+            const int j = __builtin_ctzll(live);
+            live &= live - 1;
             const uint32_t contributor = (uint32_t)(base + j + 1);
             const float4 r0 = s_rec[j * 4 + 0];  // x, y, cx, cy
             const float4 r1 = s_rec[j * 4 + 1];  // cz, w, r, g
