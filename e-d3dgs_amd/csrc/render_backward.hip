@@ -234,9 +234,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             s_rec[lane * 4 + 0] = q0;
             s_rec[lane * 4 + 1] = q1;
             keep = tile_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0, tile_x0 + (TILE - 1), tile_y0 + (TILE - 1));
-            s_rec[lane * 4 + 2] = src[2];
-            if (GEO) s_rec[lane * 4 + 3] = src[3];
-            if (COORD) {
+            if (keep) {   // the rest of the record only for entries the inner loop will visit
+                s_rec[lane * 4 + 2] = src[2];
+                if (GEO) s_rec[lane * 4 + 3] = src[3];
+            }
+            if (COORD && keep) {
                 const float4 *sc = rec_coord + (size_t)id * 3;
                 s_recc[lane * 3 + 0] = sc[0]; s_recc[lane * 3 + 1] = sc[1]; s_recc[lane * 3 + 2] = sc[2];
             }
