@@ -56,6 +56,7 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     bg = torch.ones(3, device=device)
     params = model.parameters()
     F = wl["frames"]
+    inflight = []
 
     def step(item, backward=True, coord=False):
         ci, fi = D.item_of(item, wl["cams"], F)
@@ -70,7 +71,11 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
         loss.backward()
         mse = (pkg["render"].detach() - 0.5).square().mean()
         stats = torch.stack([loss.detach(), -10.0 * torch.log10(mse), torch.ones((), device=device)])
-        D.allreduce_sum_(stats)  # the path's one collective (RCCL over xGMI): 12 bytes
+        # the path's one collective (RCCL over xGMI): 12 bytes, waited for one step later (the stream, not the host,
+        # waits), so that ranks are not re-synchronised every step
+        if inflight:
+            inflight.pop().wait()
+        inflight.append(D.allreduce_sum_async(stats))
         if dp_grads:             # opt-in: data-parallel training, mean of the ranks' gradients
             D.allreduce_gradients_(params)
         for p in params:
@@ -78,6 +83,11 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
         pkg["viewspace_points"].grad = None
         return pkg, stats
 
+    def drain():
+        while inflight:
+            inflight.pop().wait()
+
+    step.drain = drain
     return step
 
 
@@ -197,6 +207,7 @@ def main():
     _C.KEEP_LAST = True
     for k in range(a.warmup):
         step(item_at(k))
+    step.drain()
     torch.cuda.synchronize()
     log("warm-up done; bookkeeping pass")
     reff, npairs_ub, rsum = [], [], []
@@ -212,6 +223,7 @@ def main():
     L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0x1F))
     for k in range(a.steps):
         step(item_at(k))
+    step.drain()
     torch.cuda.synchronize()
     tab_ms, tab_n = (ctypes.c_double * 5)(), (ctypes.c_int * 5)()
     L.ed3dgs_profile_end_slots(tab_ms, tab_n)
@@ -225,6 +237,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(item_at(k))
+    step.drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
     slot_ms, slot_n = (ctypes.c_double * 5)(), (ctypes.c_int * 5)()

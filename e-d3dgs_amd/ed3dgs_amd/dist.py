@@ -44,6 +44,32 @@ def allreduce_sum_(t):
     return t
 
 
+class _Reduced:
+    """Handle of an all-reduce in flight.  wait() makes the CURRENT STREAM (not the host) wait for the collective on
+    RCCL, so a rank keeps enqueueing its next frame while the 12 bytes travel; gloo completes on the host."""
+
+    def __init__(self, t, wire=None, work=None):
+        self.t, self.wire, self.work = t, wire, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            if self.wire is not self.t:
+                self.t.copy_(self.wire)
+            self.work = None
+        return self.t
+
+
+def allreduce_sum_async(t):
+    """SUM over ranks of a small tensor, not waited for: the caller waits one step later (bench.py), which takes the
+    per-step collective out of the ranks' critical path -- frames differ in cost, and a blocking collective per 4 ms
+    step would run every rank at the pace of the slowest frame of each step."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        w = _on_wire(t)
+        return _Reduced(t, w, dist.all_reduce(w, op=dist.ReduceOp.SUM, async_op=True))
+    return _Reduced(t)
+
+
 def shard_items(n_items, rank, world):
     """Indices of the (camera, frame) items rank `rank` renders: i = rank (mod world)."""
     return list(range(rank, n_items, world))

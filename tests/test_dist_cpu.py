@@ -19,8 +19,11 @@ loss = sum(float(i) for i in mine); psnr = sum(2.0 * i for i in mine)
 t = D.allreduce_stats(loss, psnr, len(mine), "cpu")
 D.barrier()
 mx = D.max_over_ranks(float(rank + 1), "cpu")
+h1 = D.allreduce_sum_async(torch.tensor([float(rank + 1)]))      # two collectives in flight, waited for later
+h2 = D.allreduce_sum_async(torch.tensor([10.0 * (rank + 1)]))
+asy = [float(h1.wait()[0]), float(h2.wait()[0]), float(h1.wait()[0])]
 cams = sorted({D.item_of(i, 15, 7) for i in mine})
-print(json.dumps(dict(rank=rank, world=world, mine=mine, total=t.tolist(), mx=mx, n_pairs=len(cams))))
+print(json.dumps(dict(rank=rank, world=world, mine=mine, total=t.tolist(), mx=mx, n_pairs=len(cams), asy=asy)))
 '''
 
 
@@ -45,7 +48,7 @@ def test_two_rank_sharding_and_allreduce(tmp_path):
     assert abs(len(a) - len(b)) <= 1                                     # balanced
     want = [sum(range(n)), 2.0 * sum(range(n)), float(n)]
     for r in res:
-        assert r["world"] == 2 and r["total"] == want and r["mx"] == 2.0
+        assert r["world"] == 2 and r["total"] == want and r["mx"] == 2.0 and r["asy"] == [3.0, 30.0, 3.0]
     assert res[0]["n_pairs"] == len(a)                                   # (camera, frame) pairs are distinct
 
 
