@@ -98,8 +98,13 @@ def test_golden_values_and_grads(path):
 
 # 65,836 = 512 * 128 + 300: more block iterations than the resident grid with a small remainder, i.e. the forward's
 # (group, head) tail units run (deform_forward_pipe_kernel)
-@pytest.mark.parametrize("P,W,keep", [(5000, 128, True), (5000, 128, False), (777, 64, True), (65836, 128, True)])
-def test_against_torch_restatement(P, W, keep, monkeypatch):
+@pytest.mark.parametrize("P,W,keep,flags", [
+    (5000, 128, True, {}), (5000, 128, False, {}), (777, 64, True, {}), (65836, 128, True, {}),
+    # tail units with disabled heads (their tensors pass through with head 0's unit) and with one stage only
+    (65836, 128, True, dict(no_dr=True, no_dc=True)), (65836, 128, True, dict(no_coarse_deform=True, no_ds=True)),
+    (66100, 128, False, dict(no_fine_deform=True)),
+], ids=["5k", "5k-stateless", "w64", "tail", "tail-no_dr-no_dc", "tail-fine-only-no_ds", "tail-coarse-only-stateless"])
+def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
     keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
     _need_gpu()
@@ -108,7 +113,7 @@ def test_against_torch_restatement(P, W, keep, monkeypatch):
     import scene.deformation as SD
     from scene.deformation import deform_network
     monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", keep)
-    a = R.Args(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000)
+    a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
     torch.manual_seed(5)
     net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
     with torch.no_grad():
