@@ -2029,6 +2029,13 @@ static void fill_dev(const ed3dgs_deform_cfg *c, DeformDev &d, bool bwd)
     d.fl = frag_layout(c->W, c->E, bwd);
 }
 
+// the kept-activation backward exists for the LDS-pipelined, head-job configuration (width 128, embedding 32)
+static bool can_keep(const ed3dgs_deform_cfg *c)
+{
+    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48 && !getenv("ED3DGS_DEFORM_NO_PIPE") &&
+           !getenv("ED3DGS_DEFORM_GENERIC_WGRAD") && !getenv("ED3DGS_DEFORM_FUSED_BWD");
+}
+
 struct Workspace {
     float *frag[2]; float *fs; float *A[2], *ZR[2], *GZ[2], *GHID[2];
 };
@@ -2043,7 +2050,9 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
         const size_t PW = (size_t)(c->P > 0 ? c->P : 0) * c->W;
         for (int s = 0; s < 2; s++) {
             obtain(p, w.A[s], PW, 256); obtain(p, w.ZR[s], NHEAD * PW, 256);
-            obtain(p, w.GZ[s], NHEAD * PW, 256); obtain(p, w.GHID[s], PW, 256);
+            // g_z is stored only for the generic weight-gradient kernel; the head jobs re-form it on chip
+            if (can_keep(c)) w.GZ[s] = nullptr; else obtain(p, w.GZ[s], NHEAD * PW, 256);
+            obtain(p, w.GHID[s], PW, 256);
         }
     }
     if (ws) *ws = w;
@@ -2090,13 +2099,6 @@ static void dispatch_nt(int NT, F f)
 }  // namespace ed3
 
 using namespace ed3;
-
-// the kept-activation backward exists for the LDS-pipelined, head-job configuration (width 128, embedding 32)
-static bool can_keep(const ed3dgs_deform_cfg *c)
-{
-    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48 && !getenv("ED3DGS_DEFORM_NO_PIPE") &&
-           !getenv("ED3DGS_DEFORM_GENERIC_WGRAD") && !getenv("ED3DGS_DEFORM_FUSED_BWD");
-}
 
 extern "C" {
 
