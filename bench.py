@@ -303,7 +303,8 @@ def main():
         name = ["", "", "deform_forward_pipe_kernel<4>", "deform_dgrad_kept_kernel<4>", "deform_head_wgrad_kernel + deform_wgrad_kernel"][dom]
         roof = {"bound": "mfma", "kernel": name, "achieved": tf(avg_ms[dom]), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": tf(avg_ms[dom]) / MFMA_F32_PEAK_TFLOPS,
-                "traffic": pmc.get(name.split("<")[0].split(" ")[0]),
+                "traffic": (pmc.get("deform_head_wgrad_kernel", 0) + pmc.get("deform_wgrad_kernel", 0) or None) if dom == 4
+                           else pmc.get(name.split("<")[0].split(" ")[0]),
                 "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
                 "note": "dominant kernel of the step by time; fp32 operands on v_mfma_f32_32x32x2f32 (dense f32 MFMA peak "
                         "157.3 TFLOP/s); algorithmic flops = 2 * %d MAC per Gaussian" % macs}
