@@ -57,6 +57,9 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     params = model.parameters()
     F = wl["frames"]
     inflight = []
+    ups = [grads["color"], grads["depth"], grads["mdepth"], grads["normal"]]
+    ups_flat = torch.cat([g.reshape(-1) for g in ups])
+    one = torch.ones((), device=device)
 
     def step(item, backward=True, coord=False):
         ci, fi = D.item_of(item, wl["cams"], F)
@@ -65,12 +68,14 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
                      iter=20000, num_down_emb_c=30, num_down_emb_f=30, disable_filter3D=True)
         if not backward:
             return pkg, None
-        # fixed upstream gradients stand in for the L1/SSIM + depth-normal losses
-        loss = ((pkg["render"] * grads["color"]).sum() + (pkg["expected_depth"] * grads["depth"]).sum() +
-                (pkg["median_depth"] * grads["mdepth"]).sum() + (pkg["normal"] * grads["normal"]).sum())
-        loss.backward()
-        mse = (pkg["render"].detach() - 0.5).square().mean()
-        stats = torch.stack([loss.detach(), -10.0 * torch.log10(mse), torch.ones((), device=device)])
+        # fixed upstream gradients stand in for the L1/SSIM + depth-normal losses (the losses are outside the
+        # path): they enter the backward directly, and the scalar the ranks exchange is <outputs, upstream gradients>
+        outs = [pkg["render"], pkg["expected_depth"], pkg["median_depth"], pkg["normal"]]
+        torch.autograd.backward(outs, ups)
+        with torch.no_grad():
+            loss = torch.vdot(torch.cat([o.reshape(-1) for o in outs]), ups_flat)
+            mse = (pkg["render"] - 0.5).square().mean()
+            stats = torch.stack([loss, -10.0 * torch.log10(mse), one])
         # the path's one collective (RCCL over xGMI): 12 bytes, waited for one step later (the stream, not the host,
         # waits), so that ranks are not re-synchronised every step
         if inflight:
