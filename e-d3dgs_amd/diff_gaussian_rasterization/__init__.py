@@ -41,11 +41,25 @@ def _snapshot(args):
     return tuple(a.detach().cpu().clone() if torch.is_tensor(a) else a for a in args)
 
 
+_ZEROS = {}
+
+
+def _zeros(shape, like):
+    """Read-only zero plane standing in for the upstream gradient of an output the loss does not use (autograd would
+    otherwise allocate and fill one per call; the C ABI only reads it)."""
+    key = (tuple(shape), like.device, like.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(shape, dtype=like.dtype, device=like.device)
+    return z
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, tongue_class, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         rs = raster_settings
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as freshly filled zeros
         call = (rs.bg, means3D, colors_precomp, opacities, tongue_class, scales, rotations, rs.scale_modifier,
                 cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.image_height,
                 rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.require_coord, rs.require_depth,
@@ -77,6 +91,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geom_buf, binning_buf, img_buf,
          alpha) = ctx.saved_tensors
+        H, W = alpha.shape[-2], alpha.shape[-1]
+        z3, z1 = (3, H, W), (1, H, W)
+        grad_color = grad_color if grad_color is not None else _zeros(z3, alpha)
+        grad_coord = grad_coord if grad_coord is not None else _zeros(z3, alpha)
+        grad_mcoord = grad_mcoord if grad_mcoord is not None else _zeros(z3, alpha)
+        grad_depth = grad_depth if grad_depth is not None else _zeros(z1, alpha)
+        grad_mdepth = grad_mdepth if grad_mdepth is not None else _zeros(z1, alpha)
+        grad_alpha = grad_alpha if grad_alpha is not None else _zeros(z1, alpha)
+        grad_normal = grad_normal if grad_normal is not None else _zeros(z3, alpha)
         call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, grad_color, grad_coord,
                 grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal, normal, sh, rs.sh_degree, rs.campos,

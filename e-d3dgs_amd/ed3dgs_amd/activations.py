@@ -17,6 +17,7 @@ class _Activations(torch.autograd.Function):
         if not scales_log.is_cuda:
             raise RuntimeError("activations: tensors must be on the GPU (no CPU fallback)")
         L = _lib.lib()
+        ctx.set_materialize_grads(False)   # None (= zero for the C ABI) for outputs the loss does not reach
         s = scales_log.detach().contiguous().float()
         r = rot_raw.detach().contiguous().float()
         o = opacity_logit.detach().contiguous().float()

@@ -34,6 +34,7 @@ class _DeformFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfgd, want_sub, keep, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh):
         L = _lib.lib()
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward (NULL = zero for the C ABI)
         cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
         cfg.use_stage[0], cfg.use_stage[1] = cfgd["use_stage"]
         cfg.n_rows[0], cfg.n_rows[1] = cfgd["n_rows"]
