@@ -321,6 +321,57 @@ __global__ void __launch_bounds__(256) deform_chunk_kernel(FragArgs a)
     a.frag[s][a.fl.CH + idx] = v;
 }
 
+// Split-bf16 ("b3") fragments for the forward's v_mfma_f32_32x32x16_bf16 path: a 32 (out) x 32 (k) weight tile keeps its
+// 4 KB, as [k-step s = 0,1][part = hi,lo][lane][8 bf16]; element j of lane (r = lane & 31, h = lane >> 5) is
+// W[out r][k = 16 s + 8 (j >> 2) + 4 h + (j & 3)] -- the k order in which an accumulator tile presents its rows when its
+// registers 8s .. 8s+7 are used as the other operand (MI355X guide, "an accumulator tile as the next MFMA's operand").
+// hi = bf16(w), lo = bf16(w - hi): w = hi + lo to 2^-17.  Narrow heads' W3 tiles stay in the fp32 fragment layout (their
+// output contraction runs on the f32 4x4x1 MFMA).
+__device__ __forceinline__ uint32_t bf16_rne(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a)
+{
+    const int s = blockIdx.y;
+    if (!a.use_stage[s]) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
+    const int CHF = a.fl.ch_floats;
+    if (idx >= (size_t)a.fl.n_chunks * CHF) return;
+    const int cidx = (int)(idx / CHF), o = (int)(idx % CHF);
+    const int t = o >> 10, f = o & 1023;
+    const float *p = a.params[s];
+    const int k = cidx ? (cidx - 1) / NT : -1, nt = cidx ? (cidx - 1) % NT : 0;
+    if (cidx != 0 && t >= NT && k < 4) {   // narrow head: W3 tile in the fp32 fragment layout (deform_chunk_kernel)
+        const int lane = f & 63, kk = (f >> 6) & 15, fs = fslot(kk, lane >> 5), cl = lane & 31;
+        const int row = (t - NT) * 32 + cl;
+        a.frag[s][a.fl.CH + idx] = row < head_nk(k, a.n_sh) ? p[a.pl.W3[k] + (size_t)row * W + nt * 32 + fs] : 0.f;
+        return;
+    }
+    const int blk = f >> 8, ks = blk >> 1, part = blk & 1, lane = (f >> 2) & 63, j0 = 2 * (f & 3);
+    const int r = lane & 31, h = lane >> 5;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int j = j0 + e, kin = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float w = 0.f;
+        if (cidx == 0) {                       // F1[nt = t]: W1[:, TD:]
+            if (t < NT) w = p[a.pl.W1 + (size_t)(t * 32 + r) * ld1 + a.TD + kin];
+        } else if (t < NT) {                   // F2[k][nt][kt = t]
+            w = p[a.pl.W2[k] + (size_t)(nt * 32 + r) * W + t * 32 + kin];
+        } else {                               // F3[k = 4][ot][kt = nt]
+            const int row = (t - NT) * 32 + r;
+            if (row < head_nk(k, a.n_sh)) w = p[a.pl.W3[k] + (size_t)row * W + nt * 32 + kin];
+        }
+        const uint32_t hi = bf16_rne(w);
+        const uint32_t v = part ? bf16_rne(w - __uint_as_float(hi << 16)) : hi;
+        packed |= v << (16 * e);
+    }
+    a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // MFMA helpers
 // ------------------------------------------------------------------------------------------------------------
@@ -827,6 +878,219 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                             y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
                             if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
+                            PIPE_ADVANCE();
+                        }
+                        {   // head output bias, after the contraction (see load_bias4)
+                            const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+#pragma unroll
+                            for (int ot = 0; ot < OTMAX; ot++) {
+                                if (ot < nout) {
+                                    f32x4 bv[4];
+                                    load_bias4(bv, b3, ot, h);
+#pragma unroll
+                                    for (int r = 0; r < 16; r++) y[ot][r] += bv[r >> 2][r & 3];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; r++) csh[r] += y[0][r] * hc;
+#pragma unroll
+                        for (int r = 0; r < 8; r++) csh[16 + r] += y[1][r] * hc;
+                    }
+                }
+            }
+            float *const *dst = (s == 0) ? d.sub : d.out;
+            if (gvalid && dst[0]) {   // a tail unit owns one head's tensors (a disabled head's pass-through goes with head 0)
+                const bool w0 = konly <= 0, w1 = konly < 0 || konly == 1 || (konly == 0 && !d.enabled[1]);
+                const bool w2 = konly < 0 || konly == 2 || (konly == 0 && !d.enabled[2]);
+                const bool w3 = konly < 0 || konly == 3 || (konly == 0 && !d.enabled[3]);
+                const bool w4 = konly < 0 || konly == 4 || (konly == 0 && !d.enabled[4]);
+                if (h == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        if (w0) dst[0][(size_t)g * 3 + i] = cx[i];
+                        if (w1) dst[1][(size_t)g * 3 + i] = cs[i];
+                    }
+                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    if (w3) dst[3][g] = co;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) {
+                    const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                    if (w4 && feat < shw)
+                        *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
+                            make_float4(csh[4 * cc], csh[4 * cc + 1], csh[4 * cc + 2], csh[4 * cc + 3]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward on split-bf16 MFMA (opt-in, ED3DGS_DEFORM_BF16X3=1): every 32-wide contraction step is three
+// v_mfma_f32_32x32x16_bf16 products (w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulation) instead of sixteen
+// v_mfma_f32_32x32x2_f32: 96 MFMA cycles instead of 1024, at ~1e-5 relative accuracy (x = hi + lo to 2^-17; the
+// lo lo product is dropped) -- inside the 1e-4 the path is held to, but not the exact-fp32 results of the
+// default kernels, hence opt-in.  Same schedule, chunk pipeline, tail units and kept activations as
+// deform_forward_pipe_kernel; the narrow heads' output contraction stays on the f32 4x4x1 MFMA.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct XSplit {
+    bf16x8 h[2], l[2];   // k-steps s = 0, 1 of one 32-row tile: element j = row 16 s + 8 (j >> 2) + 4 h + (j & 3)
+};
+__device__ __forceinline__ void split_tile(const float (&v)[16], XSplit &x)
+{
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float f = v[8 * st + j];
+            const __bf16 hi = (__bf16)f;
+            x.h[st][j] = hi;
+            x.l[st][j] = (__bf16)(f - (float)hi);
+        }
+}
+// acc += W (one 32 x 32 tile in the b3 LDS format at wl) . X
+__device__ __forceinline__ f32x16 gemm_tile_b3(const float *wl, const XSplit &x, f32x16 acc, int lane)
+{
+    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        const bf16x8 wh = w[(2 * st) * 64 + lane], wlo = w[(2 * st + 1) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, x.h[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.l[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, x.h[st], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_forward_b3_kernel(DeformDev d)
+{
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_bi = (d.P + 127) / 128;
+    const int shw = 3 * d.n_sh;
+    int n_en = 0;
+    for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k] ? 1 : 0;
+    const int n_st = d.use_stage[0] + d.use_stage[1];
+    const int per_iter = n_st * (1 + n_en * NT);
+    // Block schedule.  A block iteration carries 128 Gaussians through everything and the grid is one resident round
+    // (2 blocks per CU), so ceil(n_bi / grid) iterations would leave most of the chip idle during a nearly empty last
+    // round.  When the remainder is small the host sets tail_split: the leftover groups are dealt out as (group, head)
+    // TAIL UNITS -- a block walks the trunk and ONE head of its group (both stages) and writes only that head's tensors.
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
+    const bool has_tail = d.tail_split && b < d.rem_units * n_en;
+    int tail_k = -1;
+    if (has_tail) { int e = b % n_en; for (int k = 0; k < NHEAD; k++) if (d.enabled[k] && e-- == 0) tail_k = k; }
+    const int tail_bi = d.full_rounds * G + (n_en ? b / n_en : 0);
+    (void)n_bi;
+    ED3_CHUNK_PIPE(NT, false)
+    PIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
+    for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
+        const int bi = (it < my_full) ? b + it * G : tail_bi;
+        const int konly = (it < my_full) ? -1 : tail_k;
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        float cx[3], cs[3], cr[4], co, csh[24];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { cx[i] = d.xyz[(size_t)g * 3 + i]; cs[i] = d.scales[(size_t)g * 3 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) cr[i] = d.rot[(size_t)g * 4 + i];
+        co = d.opacity[g];
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+            const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+            csh[4 * cc] = v.x; csh[4 * cc + 1] = v.y; csh[4 * cc + 2] = v.z; csh[4 * cc + 3] = v.w;
+        }
+        float eb[1][16];
+        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+        XSplit ebs;
+        split_tile(eb[0], ebs);
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (d.use_stage[s]) {
+                const float *fr = d.frag[s];
+                XSplit as[NT];
+                {
+                    const float *wb = PIPE_CUR();
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        f32x4 bv[4];
+                        load_bias4(bv, fr + d.fl.HB, nt, h);
+                        const f32x16 acc = gemm_tile_b3(wb + nt * 1024, ebs, zero_acc(), lane);
+                        float av[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) av[r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                        if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, av);
+                        split_tile(av, as[nt]);
+                    }
+                    PIPE_ADVANCE();
+                }
+                for (int k = 0; k < NHEAD; k++) {
+                    if (!d.enabled[k] || (konly >= 0 && k != konly)) continue;
+                    const float hc = d.hc[k];
+                    if (k < 4) {
+                        // narrow heads (3 / 3 / 4 / 1 outputs): the output contraction runs on the 16-block 4x4x1 MFMA --
+                        // block b = lane / 4 takes Gaussians 4 (b & 7) .. +3 and the feature this lane half holds in z at
+                        // k-slot kk, so B is z as it stands, and A (W3[i = lane & 3][that feature]) is a 4-address gather
+                        // from the head's ordinary 32x32x2 fragment.  8 cycles per step instead of 64 on a tile with 4
+                        // useful rows.
+                        f32x4 yn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                        for (int nt = 0; nt < NT; nt++) {
+                            const float *wb = PIPE_CUR();
+                            f32x4 bv[4];
+                            load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                            f32x16 acc = zero_acc();
+#pragma unroll
+                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_b3(wb + kt * 1024, as[kt], acc, lane);
+                            float z[1][16];
+#pragma unroll
+                            for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                            if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            const float *f3 = wb + NT * 1024 + 32 * h + (lane & 3);
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++)
+                                yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
+                            PIPE_ADVANCE();
+                        }
+                        const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+                        float yo[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) yo[i] = (yn[i] + __shfl_xor(yn[i], 32) + b3[i]) * hc;  // the two feature halves
+                        if (h == 0) {
+                            if (k == 0) { cx[0] += yo[0]; cx[1] += yo[1]; cx[2] += yo[2]; }
+                            else if (k == 1) { cs[0] += yo[0]; cs[1] += yo[1]; cs[2] += yo[2]; }
+                            else if (k == 2) { cr[0] += yo[0]; cr[1] += yo[1]; cr[2] += yo[2]; cr[3] += yo[3]; }
+                            else co += yo[0];
+                        }
+                    } else {
+                        f32x16 y[OTMAX];
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++) y[ot] = zero_acc();
+                        const int nout = d.ot[k];
+#pragma unroll 1
+                        for (int nt = 0; nt < NT; nt++) {
+                            const float *wb = PIPE_CUR();
+                            f32x4 bv[4];
+                            load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                            f32x16 acc = zero_acc();
+#pragma unroll
+                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_b3(wb + kt * 1024, as[kt], acc, lane);
+                            float z[1][16];
+#pragma unroll
+                            for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                            if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            XSplit zs;
+                            split_tile(z[0], zs);
+                            y[0] = gemm_tile_b3(wb + NT * 1024, zs, y[0], lane);
+                            if (nout > 1) y[1] = gemm_tile_b3(wb + (NT + 1) * 1024, zs, y[1], lane);
                             PIPE_ADVANCE();
                         }
                         {   // head output bias, after the contraction (see load_bias4)
@@ -2059,6 +2323,11 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
     return (size_t)(p - base) + 256;
 }
 
+static bool use_b3(const ed3dgs_deform_cfg *c)
+{
+    return getenv("ED3DGS_DEFORM_BF16X3") && c->E == 32 && c->W <= 128 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+}
+
 static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
                      const Workspace &w, bool bwd, hipStream_t s)
 {
@@ -2083,7 +2352,8 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     hipLaunchKernelGGL(deform_frag_kernel, dim3((unsigned)((nelem + 255) / 256), 2), dim3(256), 0, s, fa);
     if (c->E == 32 && c->W <= 128) {
         const size_t nch = (size_t)fl.n_chunks * fl.ch_floats;
-        hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+        if (!bwd && use_b3(c)) hipLaunchKernelGGL(deform_chunk_b3_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
     }
     hipLaunchKernelGGL(deform_frame_kernel, dim3(2), dim3(256), 0, s, fr);
     return check_hip(hipGetLastError(), "deform prep");
@@ -2158,7 +2428,8 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
                 for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k];
                 d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
                 d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G && !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
-                hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                if (use_b3(cfg)) hipLaunchKernelGGL((deform_forward_b3_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                else hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(G), dim3(256), lds, s, d);
                 return;
             }
         }
