@@ -372,6 +372,52 @@ __global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a)
     a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
 }
 
+// backward chunk layout (frag_layout, bwd) with the transposed tiles the kept-activation data gradient reads in the b3
+// format: F3T (rgb head only; narrow heads keep the fp32 fragment), F2T, and the transposed trunk F1T.  The forward F2
+// tiles at the head of each chunk are not read by that kernel and are left untouched.
+__global__ void __launch_bounds__(256) deform_chunk_b3_bwd_kernel(FragArgs a)
+{
+    const int s = blockIdx.y;
+    if (!a.use_stage[s]) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
+    const int CHF = a.fl.ch_floats;
+    if (idx >= (size_t)a.fl.n_chunks * CHF) return;
+    const int cidx = (int)(idx / CHF), o = (int)(idx % CHF);
+    const int t = o >> 10, f = o & 1023;
+    const float *p = a.params[s];
+    const bool last = cidx == a.fl.n_chunks - 1;
+    if (cidx == 0 || (!last && t < NT) || (last && t >= NT)) return;
+    const int k = (cidx - 1) / NT, nt = (cidx - 1) % NT;
+    if (!last && t < NT + OTMAX && k < 4) {   // narrow head: F3T in the fp32 fragment layout (deform_chunk_kernel)
+        const int lane = f & 63, kk = (f >> 6) & 15, fs = fslot(kk, lane >> 5), cl = lane & 31;
+        const int row = (t - NT) * 32 + fs;
+        a.frag[s][a.fl.CH + idx] = row < head_nk(k, a.n_sh) ? p[a.pl.W3[k] + (size_t)row * W + nt * 32 + cl] : 0.f;
+        return;
+    }
+    const int blk = f >> 8, ks = blk >> 1, part = blk & 1, lane = (f >> 2) & 63, j0 = 2 * (f & 3);
+    const int r = lane & 31, h = lane >> 5;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int j = j0 + e, kin = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float w = 0.f;
+        if (last) {                            // F1T[kt = t]: A[i = e][k = hidden feature]
+            w = p[a.pl.W1 + (size_t)(t * 32 + kin) * ld1 + a.TD + r];
+        } else if (t < NT + OTMAX) {           // F3T[k = 4][it = nt][ot]: A[i = hidden feature][k = output]
+            const int row = (t - NT) * 32 + kin;
+            if (row < head_nk(k, a.n_sh)) w = p[a.pl.W3[k] + (size_t)row * W + nt * 32 + r];
+        } else {                               // F2T[k][it][ot = nt]: A[i = in feature][k = out feature of tile nt]
+            const int itile = t - NT - OTMAX;
+            w = p[a.pl.W2[k] + (size_t)(nt * 32 + kin) * W + itile * 32 + r];
+        }
+        const uint32_t hi = bf16_rne(w);
+        const uint32_t v = part ? bf16_rne(w - __uint_as_float(hi << 16)) : hi;
+        packed |= v << (16 * e);
+    }
+    a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // MFMA helpers
 // ------------------------------------------------------------------------------------------------------------
@@ -1464,6 +1510,151 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// the same on split-bf16 MFMA (ED3DGS_DEFORM_BF16X3=1; see deform_forward_b3_kernel): W3^T g_y of the rgb head, W2^T g_z
+// and W1[:, TD:]^T g_hid as three bf16 products per 16-wide step; the narrow heads' W3^T g_y (K <= 4) stays on the f32 MFMA
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_dgrad_kept_b3_kernel(DeformDev d)
+{
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_bi = (d.P + 127) / 128;
+    const int shw = 3 * d.n_sh;
+    const bool both = d.use_stage[0] && d.use_stage[1];
+    int n_en = 0;
+    uint32_t en_pack = 0;
+    for (int k = 0; k < NHEAD; k++) if (d.enabled[k]) en_pack |= (uint32_t)k << (4 * n_en++);
+#define EN_K(e_) ((int)(en_pack >> (4 * (e_)) & 15u))
+    const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (n_en * NT + 1);
+    // block schedule as in deform_forward_pipe_kernel; here a TAIL UNIT is (group, stage): the two stages of a group
+    // are independent up to dL/d embedding, which the two units add atomically into zeroed rows (two addends: the
+    // result does not depend on their order)
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
+    const bool has_tail = d.tail_split && b < d.rem_units * 2;
+    const int tail_s = has_tail ? (b & 1) : -1;
+    const int tail_bi = d.full_rounds * G + (b >> 1);
+    (void)n_bi;
+    const size_t PW = (size_t)d.P * d.W;
+    ED3_CHUNK_PIPE_KEPT(NT)
+    PIPE_START(my_full * per_iter + (has_tail ? n_en * NT + 1 : 0), my_full, tail_s);
+    for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
+        const int bi = (it < my_full) ? b + it * G : tail_bi;
+        const int sonly = (it < my_full) ? -1 : tail_s;
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        f32x16 ge;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ge[r] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (!d.use_stage[s] || (sonly >= 0 && s != sonly)) continue;
+            const bool add_sub = (s == 0);
+            const bool add_out = (s == 1) || both || !d.use_stage[1];
+            f32x16 ga[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
+            f32x4 zn[4];
+            if (n_en > 0) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(0) * PW, d.W, g, 0, h);
+#pragma unroll 1
+            for (int e = 0; e < n_en; e++) {
+                const int k = EN_K(e);
+                const float hc = d.hc[k];
+                const int nk = d.nk[k];
+                float gy[OTMAX][16];
+#pragma unroll
+                for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
+                if (k < 4) {
+                    if (h == 0) {
+                        for (int j = 0; j < nk; j++) {
+                            float v = 0.f;
+                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
+                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
+                            gy[0][j] = v * hc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) {
+                        const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                        float4 v = make_float4(0, 0, 0, 0);
+                        if (feat < shw) {
+                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        }
+                        const int ot = cc >> 2, kk0 = 4 * (cc & 3);
+                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                    }
+                }
+                XSplit gys[OTMAX];
+                if (k >= 4) {
+#pragma unroll
+                    for (int ot = 0; ot < OTMAX; ot++) split_tile(gy[ot], gys[ot]);
+                }
+#pragma unroll 1
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x4 zc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) zc[q] = zn[q];
+                    {   // read of the next relu(z) tile flies under this tile's MFMAs
+                        const int e2 = (nt + 1 < NT) ? e : e + 1, nt2 = (nt + 1 < NT) ? nt + 1 : 0;
+                        if (e2 < n_en) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(e2) * PW, d.W, g, nt2, h);
+                    }
+                    const float *wb = PIPE_CUR();
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    if (k < 4) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++) acc = gemm_tile_b3(wb + ot * 1024, gys[ot], acc, lane);
+                    }
+                    float z[1][16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[0][r] = zc[r >> 2][r & 3] > 0.f ? acc[r] : 0.f;
+                    XSplit zs;
+                    split_tile(z[0], zs);
+#pragma unroll
+                    for (int i2 = 0; i2 < NT; i2++) ga[i2] = gemm_tile_b3(wb + (OTMAX + i2) * 1024, zs, ga[i2], lane);
+                    PIPE_ADVANCE();
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                f32x4 av[4];
+                load_tile_rows4(av, d.A[s], d.W, g, nt, h);
+                float gh[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) gh[r] = av[r >> 2][r & 3] > 0.f ? ga[nt][r] : 0.f;
+                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh);
+                XSplit ghs;
+                split_tile(gh, ghs);
+                ge = gemm_tile_b3(PIPE_CUR() + nt * 1024, ghs, ge, lane);
+            }
+            PIPE_ADVANCE();
+        }
+        if (gvalid) {
+            if (sonly >= 0) {   // tail unit: one of two addends into rows the host zeroed
+#pragma unroll
+                for (int r = 0; r < 16; r++) atomicAdd(d.g_emb + (size_t)g * d.E + (r & 3) + 8 * (r >> 2) + 4 * h, ge[r]);
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = ge[r];
+                store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+            }
+        }
+    }
+}
+
 #undef EN_K
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2329,7 +2520,7 @@ static bool use_b3(const ed3dgs_deform_cfg *c)
 }
 
 static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
-                     const Workspace &w, bool bwd, hipStream_t s)
+                     const Workspace &w, bool bwd, hipStream_t s, bool kept = false)
 {
     ParamLayout pl = param_layout(c->W, c->TD, c->E, c->n_sh);
     FragLayout fl = frag_layout(c->W, c->E, bwd);
@@ -2354,6 +2545,8 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
         const size_t nch = (size_t)fl.n_chunks * fl.ch_floats;
         if (!bwd && use_b3(c)) hipLaunchKernelGGL(deform_chunk_b3_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
         else hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+        if (bwd && kept && use_b3(c))   // the kept-activation data gradient reads its transposed tiles in the b3 format
+            hipLaunchKernelGGL(deform_chunk_b3_bwd_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
     }
     hipLaunchKernelGGL(deform_frame_kernel, dim3(2), dim3(256), 0, s, fr);
     return check_hip(hipGetLastError(), "deform prep");
@@ -2464,7 +2657,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     if (!embedding || !g_embedding) { set_error("ed3dgs_deform_backward: null embedding pointer"); return ED3DGS_ERR_INVALID; }
     Workspace w;
     carve(cfg, true, workspace, &w);
-    if (!run_prep(cfg, table, offsets, params, w, true, s)) return ED3DGS_ERR_HIP;
+    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0)) return ED3DGS_ERR_HIP;
     DeformDev d;
     std::memset(&d, 0, sizeof d);
     fill_dev(cfg, d, true);
@@ -2528,7 +2721,8 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                         okp = check_hip(hipMemsetAsync(g_embedding + r0 * cfg->E, 0, ((size_t)cfg->P - r0) * cfg->E * sizeof(float), s), "memset g_emb tail");
                         if (!okp) return;
                     }
-                    hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                    if (use_b3(cfg)) hipLaunchKernelGGL((deform_dgrad_kept_b3_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                    else hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(G), dim3(256), lds, s, d);
                     return;
                 }
                 if (piped) {
