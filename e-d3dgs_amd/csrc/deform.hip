@@ -2189,7 +2189,28 @@ struct HeadWgradArgs {
 };
 constexpr int HJ_W = 128;
 
-template <bool WIDE>
+// eight fp32 values -> the hi / lo bf16 fragments of one 16-wide k-step (see XSplit)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const __bf16 hh = (__bf16)v[j];
+        hi[j] = hh;
+        lo[j] = (__bf16)(v[j] - (float)hh);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_b3(const bf16x8 &ah, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bl, f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// B3: the contractions over the slab's 32 Gaussians (dW2, the wide head's dW3) and the wide head's g_y . W3 run as
+// split-bf16 products (two 16-wide k-steps per slab, three v_mfma_f32_32x32x16_bf16 each); the operand fragments are
+// gathered from the fp32 slabs (8 rows per lane) and split in registers; g_z, produced with the Gaussian on the register
+// index, is the A fragment as it stands.  The narrow heads' small products stay on the f32 MFMAs.
+template <bool WIDE, bool B3>
 __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int split, int nsplit, float *lds)
 {
     constexpr int KS3 = WIDE ? 24 : 2;       // k-steps of g_y . W3 (two head outputs per step; nk <= 48)
@@ -2211,7 +2232,22 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
     // in registers for the narrow heads, in LDS (rows past nk zero) for the 48-wide one
     float *w3s = gs + 32 * LDG;
     float w3f[2][WIDE ? 1 : KS3];
-    if (WIDE) {
+    if (WIDE && B3) {
+        // W3 as b3 B fragments: block ((m-tile * 3 + k-step) * 2 + part), lane (feature r, half h), element j:
+        // W3[k = 16 s + 8 (j >> 2) + 4 h + (j & 3)][m-tile * 32 + r]
+        for (int e = tid; e < 24 * 256; e += 256) {
+            const int bi = e >> 8, ln = (e >> 2) & 63, jj = e & 3, mt = bi / 6, sp = (bi % 6) >> 1, part = bi & 1;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e2 = 0; e2 < 2; e2++) {
+                const int j = 2 * jj + e2, k = 16 * sp + 8 * (j >> 2) + 4 * (ln >> 5) + (j & 3);
+                const float w = (k < nk) ? J.W3[(size_t)k * HJ_W + mt * 32 + (ln & 31)] : 0.f;
+                const uint32_t hi = bf16_rne(w);
+                packed |= (part ? bf16_rne(w - __uint_as_float(hi << 16)) : hi) << (16 * e2);
+            }
+            w3s[e] = __uint_as_float(packed);
+        }
+    } else if (WIDE) {
         for (int e = tid; e < 2 * KS3 * HJ_W; e += 256) w3s[e] = (e / HJ_W < nk) ? J.W3[e] : 0.f;
     } else {
 #pragma unroll
@@ -2282,16 +2318,31 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
         if (slab + 1 < nslab) load_regs(slab + 1);
         // g_z tiles (Gaussian on the register index), masked by relu(z) > 0
         float gz[2][16];
+        XSplit gzs[2];           // B3: g_z as the A fragments of the slab's two 16-wide k-steps
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = 0.f;
-            constexpr int UNG = WIDE ? 4 : KS3;   // the 24-step product fully unrolled pushes the wide body into scratch
+            if constexpr (WIDE && B3) {
+                const bf16x8 *w3b = reinterpret_cast<const bf16x8 *>(w3s);
+#pragma unroll 1
+                for (int sp = 0; sp < 3; sp++) {   // A: g_y of this lane's Gaussian over the k-step's 16 head outputs
+                    float v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v8[j] = gs[c * LDG + 16 * sp + 8 * (j >> 2) + 4 * h + (j & 3)];
+                    bf16x8 gyh, gyl;
+                    split8(v8, gyh, gyl);
+                    const int bi = ((2 * pmi + t) * 3 + sp) * 2;
+                    d = mfma_b3(gyh, gyl, w3b[bi * 64 + lane], w3b[(bi + 1) * 64 + lane], d);
+                }
+            } else {
+                constexpr int UNG = WIDE ? 4 : KS3;   // the 24-step product fully unrolled pushes the wide body into scratch
 #pragma unroll UNG
-            for (int kk = 0; kk < KS3; kk++) {
-                const float wv = WIDE ? w3s[(2 * kk + h) * HJ_W + (2 * pmi + t) * 32 + c] : w3f[t][WIDE ? 0 : kk];
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);  // rows past nk: zeros
+                for (int kk = 0; kk < KS3; kk++) {
+                    const float wv = WIDE ? w3s[(2 * kk + h) * HJ_W + (2 * pmi + t) * 32 + c] : w3f[t][WIDE ? 0 : kk];
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);  // rows past nk: zeros
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -2299,7 +2350,50 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                 gz[t][r] = zs[row * HJ_W + (2 * pmi + t) * 32 + c] > 0.f ? d[r] : 0.f;
                 bsum2[t] += gz[t][r];
             }
+            if constexpr (B3) split_tile(gz[t], gzs[t]);   // the fp32 tile dies here
         }
+        if constexpr (B3) {
+            // dW2 patch: A = g_z (registers 8 s .. 8 s + 7 of the tile are the k-step's Gaussian rows), B = rows of the a slab
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    float v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v8[j] = as[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * HJ_W + (2 * pni + u) * 32 + c];
+                    bf16x8 bh, bl;
+                    split8(v8, bh, bl);
+                    acc[0][u] = mfma_b3(gzs[0].h[st], gzs[0].l[st], bh, bl, acc[0][u]);
+                    acc[1][u] = mfma_b3(gzs[1].h[st], gzs[1].l[st], bh, bl, acc[1][u]);
+                    if constexpr (WIDE) __builtin_amdgcn_sched_barrier(0);   // register limit: one gathered fragment in flight
+                }
+            }
+            if constexpr (WIDE) {   // dW3 tiles: A = g_y columns, B = relu(z) columns, both gathered over the k-step's rows
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    float v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v8[j] = zs[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * HJ_W + wave * 32 + c];
+                    bf16x8 zh, zl;
+                    split8(v8, zh, zl);
+#pragma unroll
+                    for (int t = 0; t < MT3; t++) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) v8[j] = gs[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * LDG + t * 32 + c];
+                        bf16x8 gh, gl;
+                        split8(v8, gh, gl);
+                        acc3[t] = mfma_b3(gh, gl, zh, zl, acc3[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) {
+                    const int row = 2 * kk + h;
+                    acc3n = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[row * LDG + (lane & 3)], zs[row * HJ_W + wave * 32 + c], acc3n, 0, 0, 0);
+                }
+            }
+        } else {
         // dW2 patch: k-step kk multiplies Gaussian rows f(kk, h); dW3 tile(s): rows 2kk + h
         constexpr int UNR = WIDE ? 4 : 16;   // the wide instantiation is at the register limit: fewer operand reads in flight
 #pragma unroll UNR
@@ -2321,6 +2415,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                 // a 32x32x2 tile would spend 64 cycles on 4 useful rows, this spends 8
                 acc3n = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[row * LDG + (lane & 3)], zb, acc3n, 0, 0, 0);
             }
+        }
         }
         if (tid < nk) {
 #pragma unroll 8
@@ -2366,7 +2461,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
 }
 
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
-template <bool WIDE>
+template <bool WIDE, bool B3>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_kernel(HeadWgradArgs a)
 {
     extern __shared__ float hj_lds[];
@@ -2374,7 +2469,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
     const HeadJob &J = a.job[jb];
     const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
-    head_wgrad_body<WIDE>(J, a.P, split, nsplit, hj_lds);
+    head_wgrad_body<WIDE, B3>(J, a.P, split, nsplit, hj_lds);
 }
 
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
@@ -2826,11 +2921,18 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         }
         ha.blk_begin[ha.njobs] = nblk;
         const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + (wide ? 48 * HJ_W : 0)) * sizeof(float);  // z, a, g_y slabs (+ W3)
+        const bool b3 = use_b3(cfg);
         if (wide) {
-            if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
-            hipLaunchKernelGGL(deform_head_wgrad_kernel<true>, dim3(nblk), dim3(256), lds, s, ha);
+            // the wide body stays on the f32 MFMA for now: its split-bf16 instantiation needs more registers than two
+            // waves per SIMD leave (152 B of scratch per lane made it slower, 0.50 vs 0.33 ms); ED3DGS_DEFORM_B3_WIDE=1 runs it
+            const bool b3w = b3 && getenv("ED3DGS_DEFORM_B3_WIDE");
+            const void *fn = b3w ? (const void *)deform_head_wgrad_kernel<true, true> : (const void *)deform_head_wgrad_kernel<true, false>;
+            if (!check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
+            if (b3w) hipLaunchKernelGGL((deform_head_wgrad_kernel<true, true>), dim3(nblk), dim3(256), lds, s, ha);
+            else hipLaunchKernelGGL((deform_head_wgrad_kernel<true, false>), dim3(nblk), dim3(256), lds, s, ha);
         } else {
-            hipLaunchKernelGGL(deform_head_wgrad_kernel<false>, dim3(nblk), dim3(256), lds, s, ha);
+            if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
+            else hipLaunchKernelGGL((deform_head_wgrad_kernel<false, false>), dim3(nblk), dim3(256), lds, s, ha);
         }
     }
     if (pw) prof_stop(ED3DGS_PROF_DEFORM_WGRAD, s);
