@@ -52,9 +52,14 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+@pytest.mark.parametrize("b3", [False, True], ids=["fp32", "split-bf16"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
-def test_golden_values_and_grads(path):
+def test_golden_values_and_grads(path, b3, monkeypatch):
+    """Against the reference's own outputs; b3 = the opt-in split-bf16 MFMA kernels (ED3DGS_DEFORM_BF16X3=1), held to the
+    same 1e-4."""
     _need_gpu()
+    if b3:
+        monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
     z, a = _load(path)
     if int(z["cfg_D"]) > 1:
         net = _build(z, a)
@@ -103,7 +108,10 @@ def test_golden_values_and_grads(path):
     # tail units with disabled heads (their tensors pass through with head 0's unit) and with one stage only
     (65836, 128, True, dict(no_dr=True, no_dc=True)), (65836, 128, True, dict(no_coarse_deform=True, no_ds=True)),
     (66100, 128, False, dict(no_fine_deform=True)),
-], ids=["5k", "5k-stateless", "w64", "tail", "tail-no_dr-no_dc", "tail-fine-only-no_ds", "tail-coarse-only-stateless"])
+    # the opt-in split-bf16 MFMA kernels (forward, kept data gradient, narrow-head weight gradients)
+    (5000, 128, True, dict(b3=True)), (65836, 128, True, dict(b3=True, no_dr=True)), (777, 64, True, dict(b3=True)),
+], ids=["5k", "5k-stateless", "w64", "tail", "tail-no_dr-no_dc", "tail-fine-only-no_ds", "tail-coarse-only-stateless",
+        "5k-split-bf16", "tail-split-bf16-no_dr", "w64-split-bf16"])
 def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
     keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
@@ -113,6 +121,9 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     import scene.deformation as SD
     from scene.deformation import deform_network
     monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", keep)
+    flags = dict(flags)
+    if flags.pop("b3", False):
+        monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
     a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
     torch.manual_seed(5)
     net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
