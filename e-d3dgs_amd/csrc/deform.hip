@@ -96,6 +96,7 @@ struct DeformDev {
     // backward
     const float *g[5], *gs[5];
     float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
+    unsigned long long *MK[2];  // kept sign masks [1 + 5][P][2]: bit 16 nt + r of word (slot, g, h) = (tile nt, register r) > 0
     float *g_emb;
     int full_rounds, rem_units, tail_split;  // forward block schedule (see deform_forward_pipe_kernel)
     int keep;      // forward writes a = relu(hid) and relu(z_k) for the backward (activations kept instead of re-formed)
@@ -792,6 +793,14 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
 // Bias handling in the LDS-pipelined kernels: the bias is fetched into registers when a tile starts and ADDED AFTER the
 // tile's MFMAs.  Seeding the accumulator with it would put a global load in front of the first MFMA, and its
 // s_waitcnt vmcnt(0) would also wait for the weight chunk prefetched just before (loads retire in order).
+// bit r = (v[r] > 0): what the data gradient needs of a kept relu tile
+__device__ __forceinline__ uint32_t mask16(const float (&v)[16])
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) m |= (v[r] > 0.f ? 1u : 0u) << r;
+    return m;
+}
 __device__ __forceinline__ f32x16 zero_acc()
 {
     f32x16 acc;
@@ -857,6 +866,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int s = 0; s < 2; s++) {
             if (d.use_stage[s]) {
                 const float *fr = d.frag[s];
+                unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
                 float a[NT][16];
                 {
                     const float *wb = PIPE_CUR();
@@ -868,11 +878,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                         for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                         if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
+                        if (d.keep) mka |= (unsigned long long)mask16(a[nt]) << (16 * nt);
                     }
                     PIPE_ADVANCE();
                 }
+                if (d.keep && gvalid) d.MK[s][((size_t)g) * 2 + h] = mka;
                 for (int k = 0; k < NHEAD; k++) {
                     if (!d.enabled[k] || (konly >= 0 && k != konly)) continue;
+                    unsigned long long mkz = 0;   // sign mask of relu(z_k)
                     const float hc = d.hc[k];
                     if (k < 4) {
                         // narrow heads (3 / 3 / 4 / 1 outputs): the output contraction runs on the 16-block 4x4x1 MFMA --
@@ -891,12 +904,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
                             const float *f3 = wb + NT * 1024 + 32 * h + (lane & 3);
 #pragma unroll
                             for (int kk = 0; kk < 16; kk++)
                                 yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
                             PIPE_ADVANCE();
                         }
+                        if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
                         float yo[4];
 #pragma unroll
@@ -922,10 +937,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
                             y[0] = gemm_tile_lds<1>(wb + NT * 1024, z, y[0], lane);
                             if (nout > 1) y[1] = gemm_tile_lds<1>(wb + (NT + 1) * 1024, z, y[1], lane);
                             PIPE_ADVANCE();
                         }
+                        if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         {   // head output bias, after the contraction (see load_bias4)
                             const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
 #pragma unroll
@@ -1062,6 +1079,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int s = 0; s < 2; s++) {
             if (d.use_stage[s]) {
                 const float *fr = d.frag[s];
+                unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
                 XSplit as[NT];
                 {
                     const float *wb = PIPE_CUR();
@@ -1074,12 +1092,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                         for (int r = 0; r < 16; r++) av[r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                         if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, av);
+                        if (d.keep) mka |= (unsigned long long)mask16(av) << (16 * nt);
                         split_tile(av, as[nt]);
                     }
                     PIPE_ADVANCE();
                 }
+                if (d.keep && gvalid) d.MK[s][((size_t)g) * 2 + h] = mka;
                 for (int k = 0; k < NHEAD; k++) {
                     if (!d.enabled[k] || (konly >= 0 && k != konly)) continue;
+                    unsigned long long mkz = 0;   // sign mask of relu(z_k)
                     const float hc = d.hc[k];
                     if (k < 4) {
                         // narrow heads (3 / 3 / 4 / 1 outputs): the output contraction runs on the 16-block 4x4x1 MFMA --
@@ -1100,12 +1121,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
                             const float *f3 = wb + NT * 1024 + 32 * h + (lane & 3);
 #pragma unroll
                             for (int kk = 0; kk < 16; kk++)
                                 yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
                             PIPE_ADVANCE();
                         }
+                        if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
                         float yo[4];
 #pragma unroll
@@ -1133,12 +1156,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
                             XSplit zs;
                             split_tile(z[0], zs);
                             y[0] = gemm_tile_b3(wb + NT * 1024, zs, y[0], lane);
                             if (nout > 1) y[1] = gemm_tile_b3(wb + (NT + 1) * 1024, zs, y[1], lane);
                             PIPE_ADVANCE();
                         }
+                        if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         {   // head output bias, after the contraction (see load_bias4)
                             const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
 #pragma unroll
@@ -1417,11 +1442,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
-            f32x4 zn[4];
-            if (n_en > 0) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(0) * PW, d.W, g, 0, h);
+            // the kept sign masks (16 bytes per Gaussian, head and stage) stand in for the relu tiles themselves
+            const unsigned long long *mk = d.MK[s] + (size_t)g * 2 + h;
+            const unsigned long long mka = mk[0];
+            unsigned long long mkn = n_en > 0 ? mk[(size_t)(1 + EN_K(0)) * d.P * 2] : 0ull;
 #pragma unroll 1
             for (int e = 0; e < n_en; e++) {
                 const int k = EN_K(e);
+                const unsigned long long mkz = mkn;
+                if (e + 1 < n_en) mkn = mk[(size_t)(1 + EN_K(e + 1)) * d.P * 2];   // next head's mask flies under this head's MFMAs
                 const float hc = d.hc[k];
                 const int nk = d.nk[k];
                 float gy[OTMAX][16];
@@ -1453,13 +1482,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
 #pragma unroll 1
                 for (int nt = 0; nt < NT; nt++) {
-                    f32x4 zc[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) zc[q] = zn[q];
-                    {   // read of the next relu(z) tile flies under this tile's MFMAs
-                        const int e2 = (nt + 1 < NT) ? e : e + 1, nt2 = (nt + 1 < NT) ? nt + 1 : 0;
-                        if (e2 < n_en) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(e2) * PW, d.W, g, nt2, h);
-                    }
                     const float *wb = PIPE_CUR();
                     f32x16 acc;
 #pragma unroll
@@ -1477,7 +1499,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                     float z[1][16];
 #pragma unroll
-                    for (int r = 0; r < 16; r++) z[0][r] = zc[r >> 2][r & 3] > 0.f ? acc[r] : 0.f;
+                    for (int r = 0; r < 16; r++) z[0][r] = (mkz >> (16 * nt + r)) & 1ull ? acc[r] : 0.f;
 #pragma unroll
                     for (int i2 = 0; i2 < NT; i2++)
                         ga[i2] = gemm_tile_lds<1>(wb + (OTMAX + i2) * 1024, z, ga[i2], lane);
@@ -1487,10 +1509,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             float gh[NT][16];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                f32x4 av[4];
-                load_tile_rows4(av, d.A[s], d.W, g, nt, h);
 #pragma unroll
-                for (int r = 0; r < 16; r++) gh[nt][r] = av[r >> 2][r & 3] > 0.f ? ga[nt][r] : 0.f;
+                for (int r = 0; r < 16; r++) gh[nt][r] = (mka >> (16 * nt + r)) & 1ull ? ga[nt][r] : 0.f;
                 if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh[nt]);
             }
             ge = gemm_tile_lds<NT>(PIPE_CUR(), gh, ge, lane);
@@ -1557,11 +1577,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
-            f32x4 zn[4];
-            if (n_en > 0) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(0) * PW, d.W, g, 0, h);
+            // the kept sign masks (16 bytes per Gaussian, head and stage) stand in for the relu tiles themselves
+            const unsigned long long *mk = d.MK[s] + (size_t)g * 2 + h;
+            const unsigned long long mka = mk[0];
+            unsigned long long mkn = n_en > 0 ? mk[(size_t)(1 + EN_K(0)) * d.P * 2] : 0ull;
 #pragma unroll 1
             for (int e = 0; e < n_en; e++) {
                 const int k = EN_K(e);
+                const unsigned long long mkz = mkn;
+                if (e + 1 < n_en) mkn = mk[(size_t)(1 + EN_K(e + 1)) * d.P * 2];   // next head's mask flies under this head's MFMAs
                 const float hc = d.hc[k];
                 const int nk = d.nk[k];
                 float gy[OTMAX][16];
@@ -1598,13 +1622,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
 #pragma unroll 1
                 for (int nt = 0; nt < NT; nt++) {
-                    f32x4 zc[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) zc[q] = zn[q];
-                    {   // read of the next relu(z) tile flies under this tile's MFMAs
-                        const int e2 = (nt + 1 < NT) ? e : e + 1, nt2 = (nt + 1 < NT) ? nt + 1 : 0;
-                        if (e2 < n_en) load_tile_rows4(zn, d.ZR[s] + (size_t)EN_K(e2) * PW, d.W, g, nt2, h);
-                    }
                     const float *wb = PIPE_CUR();
                     f32x16 acc;
 #pragma unroll
@@ -1619,7 +1636,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                     float z[1][16];
 #pragma unroll
-                    for (int r = 0; r < 16; r++) z[0][r] = zc[r >> 2][r & 3] > 0.f ? acc[r] : 0.f;
+                    for (int r = 0; r < 16; r++) z[0][r] = (mkz >> (16 * nt + r)) & 1ull ? acc[r] : 0.f;
                     XSplit zs;
                     split_tile(z[0], zs);
 #pragma unroll
@@ -1629,11 +1646,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                f32x4 av[4];
-                load_tile_rows4(av, d.A[s], d.W, g, nt, h);
                 float gh[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) gh[r] = av[r >> 2][r & 3] > 0.f ? ga[nt][r] : 0.f;
+                for (int r = 0; r < 16; r++) gh[r] = (mka >> (16 * nt + r)) & 1ull ? ga[nt][r] : 0.f;
                 if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh);
                 XSplit ghs;
                 split_tile(gh, ghs);
@@ -2588,6 +2603,7 @@ static bool can_keep(const ed3dgs_deform_cfg *c)
 
 struct Workspace {
     float *frag[2]; float *fs; float *A[2], *ZR[2], *GZ[2], *GHID[2];
+    unsigned long long *MK[2];
 };
 static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace *ws)
 {
@@ -2603,6 +2619,7 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
             // g_z is stored only for the generic weight-gradient kernel; the head jobs re-form it on chip
             if (can_keep(c)) w.GZ[s] = nullptr; else obtain(p, w.GZ[s], NHEAD * PW, 256);
             obtain(p, w.GHID[s], PW, 256);
+            obtain(p, w.MK[s], (size_t)(1 + NHEAD) * (c->P > 0 ? c->P : 0) * 2, 256);
         }
     }
     if (ws) *ws = w;
@@ -2697,7 +2714,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     fill_dev(cfg, d, false);
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.keep = keep ? 1 : 0;
-    if (keep) for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; }
+    if (keep) for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.MK[st] = w.MK[st]; }
     d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh;
     float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
     float *subs[5] = {sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh};
@@ -2761,7 +2778,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     const float *gg[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
     const float *gsub[5] = {gs_xyz, gs_scales, gs_rot, gs_opacity, gs_sh};
     for (int i = 0; i < 5; i++) { d.g[i] = gg[i]; d.gs[i] = gsub[i]; }
-    for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.GZ[st] = w.GZ[st]; d.GHID[st] = w.GHID[st]; }
+    for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.GZ[st] = w.GZ[st]; d.GHID[st] = w.GHID[st]; d.MK[st] = w.MK[st]; }
     d.g_emb = g_embedding;
     d.ablate = getenv("ED3DGS_FB_ABLATE") ? atoi(getenv("ED3DGS_FB_ABLATE")) : 0;
     d.store_gz = 1;
