@@ -2225,7 +2225,7 @@ __device__ __forceinline__ f32x16 mfma_b3(const bf16x8 &ah, const bf16x8 &al, co
 // split-bf16 products (two 16-wide k-steps per slab, three v_mfma_f32_32x32x16_bf16 each); the operand fragments are
 // gathered from the fp32 slabs (8 rows per lane) and split in registers; g_z, produced with the Gaussian on the register
 // index, is the A fragment as it stands.  The narrow heads' small products stay on the f32 MFMAs.
-template <bool WIDE, bool B3>
+template <bool WIDE, bool B3, bool DW3 = true>
 __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int split, int nsplit, float *lds)
 {
     constexpr int KS3 = WIDE ? 24 : 2;       // k-steps of g_y . W3 (two head outputs per step; nk <= 48)
@@ -2383,7 +2383,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                     if constexpr (WIDE) __builtin_amdgcn_sched_barrier(0);   // register limit: one gathered fragment in flight
                 }
             }
-            if constexpr (WIDE) {   // dW3 tiles: A = g_y columns, B = relu(z) columns, both gathered over the k-step's rows
+            if constexpr (WIDE && DW3) {   // dW3 tiles: A = g_y columns, B = relu(z) columns, both gathered over the k-step's rows
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
                     float v8[8];
@@ -2401,7 +2401,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-            } else {
+            } else if constexpr (!WIDE) {
 #pragma unroll
                 for (int kk = 0; kk < 16; kk++) {
                     const int row = 2 * kk + h;
@@ -2432,7 +2432,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             }
         }
         }
-        if (tid < nk) {
+        if (DW3 && tid < nk) {
 #pragma unroll 8
             for (int r = 0; r < 32; r++) bsum3 += gs[r * LDG + tid];
         }
@@ -2450,7 +2450,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                 const int mi = (2 * pmi + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 atomicAdd(J.dW2 + (size_t)mi * HJ_W + (2 * pni + u) * 32 + c, acc[t][u][r]);
             }
-    if constexpr (WIDE) {
+    if constexpr (WIDE && DW3) {
 #pragma unroll
         for (int t = 0; t < MT3; t++)
 #pragma unroll
@@ -2458,7 +2458,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                 const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, acc3[t][r]);
             }
-    } else {
+    } else if constexpr (!WIDE) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {   // the two row-parity blocks of a feature group sit 32 lanes apart
             const float v = acc3n[i] + __shfl_xor(acc3n[i], 32);
@@ -2472,11 +2472,11 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             if (h == 0) atomicAdd(J.db2 + (2 * pmi + t) * 32 + c, v);
         }
     }
-    if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
+    if (DW3 && tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
-template <bool WIDE, bool B3>
+template <bool WIDE, bool B3, bool DW3 = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_kernel(HeadWgradArgs a)
 {
     extern __shared__ float hj_lds[];
@@ -2484,7 +2484,109 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
     const HeadJob &J = a.job[jb];
     const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
-    head_wgrad_body<WIDE, B3>(J, a.P, split, nsplit, hj_lds);
+    head_wgrad_body<WIDE, B3, DW3>(J, a.P, split, nsplit, hj_lds);
+}
+
+// dW3 / db3 of the wide head on their own (split-bf16 mode): with them the wide body needs more registers than two waves
+// per SIMD leave.  Block = (job, range of Gaussians); slabs of relu(z) and g_y staged in LDS; wave w owns the feature
+// tile w of both 32-row tiles of dW3.  Re-reads relu(z) (512 B per Gaussian and stage) -- cheaper than the spills.
+__global__ void __launch_bounds__(256) deform_dw3_wide_kernel(HeadWgradArgs a)
+{
+    extern __shared__ float hj_lds[];
+    constexpr int LDG = 65, NG = 6;
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    const HeadJob &J = a.job[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = J.nk, P = a.P;
+    float *zs = hj_lds, *gs = hj_lds + 32 * HJ_W;
+    const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int p0 = split * chunk, p1 = min(P, p0 + chunk);
+    if (p0 >= p1) return;
+    const int nslab = (p1 - p0 + 31) / 32;
+    for (int e = tid; e < 32 * LDG; e += 256) gs[e] = 0.f;
+    f32x16 acc3[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc3[0][r] = acc3[1][r] = 0.f;
+    float bsum3 = 0.f;
+    f32x4 zv[4];
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 gv, g2v;
+    const bool has_g2 = J.G2 != nullptr;
+    const int gcount = 32 * nk;
+    auto load_regs = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = tid + 256 * i, r = e >> 5, cc = (e & 31) * 4;
+            zv[i] = *reinterpret_cast<const f32x4 *>(J.ZR + (size_t)min(r0 + r, p1 - 1) * HJ_W + cc);
+        }
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int e = tid + 256 * i;
+            const size_t o = (size_t)r0 * nk + min(e, (p1 - r0) * nk - 1);
+            gv[i] = J.G[o];
+            if (has_g2) g2v[i] = J.G2[o];
+        }
+    };
+    auto store_lds = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = tid + 256 * i, r = e >> 5, cc = (e & 31) * 4;
+            *reinterpret_cast<f32x4 *>(zs + r * HJ_W + cc) = zv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int e = tid + 256 * i;
+            if (e < gcount) {
+                const int r = e / nk, cc = e - r * nk;
+                float v = gv[i];
+                if (has_g2) v += g2v[i];
+                gs[r * LDG + cc] = (r0 + r < p1) ? v * J.gscale : 0.f;
+            }
+        }
+    };
+    __syncthreads();
+    load_regs(0);
+    store_lds(0);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; slab++) {
+        if (slab + 1 < nslab) load_regs(slab + 1);
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v8[j] = zs[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * HJ_W + wave * 32 + c];
+            bf16x8 zh, zl;
+            split8(v8, zh, zl);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v8[j] = gs[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * LDG + t * 32 + c];
+                bf16x8 gh, gl;
+                split8(v8, gh, gl);
+                acc3[t] = mfma_b3(gh, gl, zh, zl, acc3[t]);
+            }
+        }
+        if (tid < nk) {
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) bsum3 += gs[r * LDG + tid];
+        }
+        __syncthreads();
+        if (slab + 1 < nslab) store_lds(slab + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, acc3[t][r]);
+        }
+    if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
@@ -2940,13 +3042,18 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + (wide ? 48 * HJ_W : 0)) * sizeof(float);  // z, a, g_y slabs (+ W3)
         const bool b3 = use_b3(cfg);
         if (wide) {
-            // the wide body stays on the f32 MFMA for now: its split-bf16 instantiation needs more registers than two
-            // waves per SIMD leave (152 B of scratch per lane made it slower, 0.50 vs 0.33 ms); ED3DGS_DEFORM_B3_WIDE=1 runs it
-            const bool b3w = b3 && getenv("ED3DGS_DEFORM_B3_WIDE");
-            const void *fn = b3w ? (const void *)deform_head_wgrad_kernel<true, true> : (const void *)deform_head_wgrad_kernel<true, false>;
+            const void *fn = b3 ? (const void *)deform_head_wgrad_kernel<true, true, false> : (const void *)deform_head_wgrad_kernel<true, false>;
             if (!check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
-            if (b3w) hipLaunchKernelGGL((deform_head_wgrad_kernel<true, true>), dim3(nblk), dim3(256), lds, s, ha);
-            else hipLaunchKernelGGL((deform_head_wgrad_kernel<true, false>), dim3(nblk), dim3(256), lds, s, ha);
+            if (b3) {   // split-bf16: dW2/db2 here, dW3/db3 in their own launch (register budget)
+                hipLaunchKernelGGL((deform_head_wgrad_kernel<true, true, false>), dim3(nblk), dim3(256), lds, s, ha);
+                HeadWgradArgs h3 = ha;
+                int nb3 = 0;
+                for (int q = 0; q < h3.njobs; q++) { h3.blk_begin[q] = nb3; nb3 += std::max(1, std::min((cfg->P + 127) / 128, 256 / h3.njobs)); }
+                h3.blk_begin[h3.njobs] = nb3;
+                hipLaunchKernelGGL(deform_dw3_wide_kernel, dim3(nb3), dim3(256), (size_t)(32 * HJ_W + 32 * 65) * sizeof(float), s, h3);
+            } else {
+                hipLaunchKernelGGL((deform_head_wgrad_kernel<true, false>), dim3(nblk), dim3(256), lds, s, ha);
+            }
         } else {
             if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
             else hipLaunchKernelGGL((deform_head_wgrad_kernel<false, false>), dim3(nblk), dim3(256), lds, s, ha);
