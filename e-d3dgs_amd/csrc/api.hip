@@ -182,16 +182,28 @@ int ed3dgs_rasterize_forward(
     if (!ok("preprocess")) return ED3DGS_ERR_HIP;
     if (!run_scan(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.point_offsets, P, s)) return ED3DGS_ERR_HIP;
     if (!ok("scan")) return ED3DGS_ERR_HIP;
-    // binning level 1 (binning.hip): Gaussians by depth, then the instance offsets in that order; enqueued before the
-    // read-back below so it runs under the host's wait
+    // The one read-back of the path (CR/rasterizer_impl.cu:359: the instance count sizes the binning buffers).  The copy
+    // goes to pinned memory and is followed by an event; the work that does not need the count -- binning level 1
+    // (binning.hip: Gaussians by depth, then the instance offsets in that order) and clearing the tile ranges -- is
+    // enqueued BEHIND the copy, and the host waits for the event only.  By the time the GPU has finished the level-1
+    // sort the host has allocated the binning buffers and enqueued the rest, so the stream never runs dry (the
+    // reference's cudaMemcpy drains it).
+    static thread_local struct Readback {
+        uint32_t *host = nullptr;
+        hipEvent_t ev = nullptr;
+    } rb;
+    if (!rb.host) {
+        if (!check_hip(hipHostMalloc((void **)&rb.host, 64, hipHostMallocDefault), "pinned read-back buffer") ||
+            !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
+    }
+    if (!check_hip(hipMemcpyAsync(rb.host, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
     if (!ok("depth order")) return ED3DGS_ERR_HIP;
-
-    // the one blocking read-back of the path (CR/rasterizer_impl.cu:359)
-    uint32_t num_rendered_u = 0;
-    if (!check_hip(hipMemcpyAsync(&num_rendered_u, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipStreamSynchronize(s), "sync num_rendered")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
+    const uint32_t num_rendered_u = *rb.host;
     if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
     const int R = (int)num_rendered_u;
 
@@ -204,7 +216,6 @@ int ed3dgs_rasterize_forward(
     const int bit = (int)higher_msb((uint32_t)T);
     if (!run_sort(bin.sort_space, bin.sort_size, bin.tile_keys_unsorted, bin.tile_keys, bin.point_list_unsorted, bin.point_list, R, bit, s)) return ED3DGS_ERR_HIP;
     if (!ok("sort")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
     launch_identify_tile_ranges(R, bin.tile_keys, img.ranges, s);
     if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
 
