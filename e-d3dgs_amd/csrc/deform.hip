@@ -2589,6 +2589,16 @@ __global__ void __launch_bounds__(256) deform_dw3_wide_kernel(HeadWgradArgs a)
     if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
+struct ZeroArgs {
+    float *p[4];
+    size_t n[4];
+};
+__global__ void __launch_bounds__(256) deform_zero_kernel(ZeroArgs a)
+{
+    for (int q = 0; q < 4; q++)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[q]; i += (size_t)gridDim.x * blockDim.x) a.p[q][i] = 0.f;
+}
+
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
 struct FrameBwdArgs {
     int W, E, TD, max_emb, num_offsets, cam_no;
@@ -2863,10 +2873,14 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     if (workspace_bytes < carve(cfg, true, nullptr, nullptr)) { set_error("ed3dgs_deform_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     const ParamLayout pl = param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh);
-    if (!check_hip(hipMemsetAsync(g_table, 0, (size_t)cfg->max_embeddings * cfg->TD * sizeof(float), s), "memset g_table")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipMemsetAsync(g_offsets, 0, (size_t)cfg->num_offsets * sizeof(float), s), "memset g_offsets")) return ED3DGS_ERR_HIP;
-    for (int st = 0; st < 2; st++)
-        if (cfg->use_stage[st] && !check_hip(hipMemsetAsync(gparams[st], 0, pl.total * sizeof(float), s), "memset gparams")) return ED3DGS_ERR_HIP;
+    {   // the accumulated outputs start from zero: one launch for the four of them
+        ZeroArgs za;
+        za.p[0] = g_table; za.n[0] = (size_t)cfg->max_embeddings * cfg->TD;
+        za.p[1] = g_offsets; za.n[1] = (size_t)cfg->num_offsets;
+        for (int st = 0; st < 2; st++) { za.p[2 + st] = cfg->use_stage[st] ? gparams[st] : nullptr; za.n[2 + st] = cfg->use_stage[st] ? pl.total : 0; }
+        hipLaunchKernelGGL(deform_zero_kernel, dim3(256), dim3(256), 0, s, za);
+        if (!check_hip(hipGetLastError(), "zero gradients")) return ED3DGS_ERR_HIP;
+    }
     if (cfg->P == 0) return 0;
     if (!embedding || !g_embedding) { set_error("ed3dgs_deform_backward: null embedding pointer"); return ED3DGS_ERR_INVALID; }
     Workspace w;
