@@ -79,7 +79,7 @@ __host__ __device__ inline FragLayout frag_layout(int W, int E, bool bwd)
     L.ch_floats = (bwd ? 2 * NT + OTMAX : NT + OTMAX) * 1024;
     L.n_chunks = 1 + NHEAD * NT + (bwd ? 1 : 0);
     o = (o + 63) & ~(size_t)63;
-    L.CH = o; if (E == 32 && NT <= 4) o += (size_t)L.n_chunks * L.ch_floats;
+    L.CH = o; if (E == 32 && NT <= 4) o += (size_t)L.n_chunks * ((L.ch_floats / 2 * 3 + 1023) & ~1023);  // room for 3-piece split tiles (1536 floats)
     L.total = (o + 63) & ~(size_t)63;
     return L;
 }
@@ -333,25 +333,29 @@ __device__ __forceinline__ uint32_t bf16_rne(float x)
     const uint32_t u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
+template <int NP>   // pieces per value: 2 (hi, lo) or 3 (x = p0 + p1 + p2 exactly: 3 x 8 significant bits)
 __global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a)
 {
     const int s = blockIdx.y;
     if (!a.use_stage[s]) return;
+    constexpr int TS = NP * 512;   // floats per tile: [k-step 2][piece NP][lane 64][8 bf16]
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
-    const int CHF = a.fl.ch_floats;
+    const int CHF = ((NT + OTMAX) * TS + 1023) & ~1023;   // chunk stride (ChunkSeq)
     if (idx >= (size_t)a.fl.n_chunks * CHF) return;
     const int cidx = (int)(idx / CHF), o = (int)(idx % CHF);
-    const int t = o >> 10, f = o & 1023;
+    const int t = o / TS, f = o % TS;
+    if (t >= NT + OTMAX) return;                          // padding
     const float *p = a.params[s];
     const int k = cidx ? (cidx - 1) / NT : -1, nt = cidx ? (cidx - 1) % NT : 0;
     if (cidx != 0 && t >= NT && k < 4) {   // narrow head: W3 tile in the fp32 fragment layout (deform_chunk_kernel)
+        if (f >= 1024) return;
         const int lane = f & 63, kk = (f >> 6) & 15, fs = fslot(kk, lane >> 5), cl = lane & 31;
         const int row = (t - NT) * 32 + cl;
         a.frag[s][a.fl.CH + idx] = row < head_nk(k, a.n_sh) ? p[a.pl.W3[k] + (size_t)row * W + nt * 32 + fs] : 0.f;
         return;
     }
-    const int blk = f >> 8, ks = blk >> 1, part = blk & 1, lane = (f >> 2) & 63, j0 = 2 * (f & 3);
+    const int blk = f >> 8, ks = blk / NP, part = blk % NP, lane = (f >> 2) & 63, j0 = 2 * (f & 3);
     const int r = lane & 31, h = lane >> 5;
     uint32_t packed = 0;
 #pragma unroll
@@ -366,8 +370,13 @@ __global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a)
             const int row = (t - NT) * 32 + r;
             if (row < head_nk(k, a.n_sh)) w = p[a.pl.W3[k] + (size_t)row * W + nt * 32 + kin];
         }
-        const uint32_t hi = bf16_rne(w);
-        const uint32_t v = part ? bf16_rne(w - __uint_as_float(hi << 16)) : hi;
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < NP; q++) {         // residual chain: piece q = bf16(w - p0 - ... - p_{q-1})
+            v = bf16_rne(w);
+            if (q == part) break;
+            w -= __uint_as_float(v << 16);
+        }
         packed |= v << (16 * e);
     }
     a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
@@ -721,7 +730,7 @@ __device__ __forceinline__ f32x16 gemm_tile_lds(const float *wl, const float (&x
 
 // order in which the kernels consume chunks: per block iteration, per used stage: chunk 0, (k, nt) for enabled heads,
 // [last chunk if BWD]
-template <int NT, bool BWD>
+template <int NT, bool BWD, int TS = 1024>
 struct ChunkSeq {
     int s, k, nt;  // k = -1: trunk chunk, k = NHEAD: transposed trunk chunk (BWD)
     int full_left, tail_k;   // block iterations still to walk with every head; after them only head tail_k (tail unit)
@@ -732,7 +741,7 @@ struct ChunkSeq {
     __device__ __forceinline__ const float *next(const DeformDev &d)
     {
         const int n_chunks = 1 + NHEAD * NT + (BWD ? 1 : 0);
-        const int ch = (BWD ? 2 * NT + OTMAX : NT + OTMAX) * 1024;
+        const int ch = ((BWD ? 2 * NT + OTMAX : NT + OTMAX) * TS + 1023) & ~1023;   // chunk stride: whole 4-KB staging rows
         const int cidx = (k < 0) ? 0 : (k >= NHEAD ? n_chunks - 1 : 1 + k * NT + nt);
         const float *p = d.frag[s] + d.fl.CH + (size_t)cidx * ch;
         // advance
@@ -770,6 +779,12 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
     constexpr int PIPE_NF4 = PIPE_CHF / 4 / 256;                                                  \
     f32x4 pipe_st[PIPE_NF4];                                                                      \
     ChunkSeq<NT_, BWD_> pipe_seq;                                                                 \
+    int pipe_n = 0, pipe_total = 0;
+#define ED3_CHUNK_PIPE_TS(NT_, TS_)                                                                \
+    constexpr int PIPE_CHF = (((NT_) + OTMAX) * (TS_) + 1023) & ~1023;                             \
+    constexpr int PIPE_NF4 = PIPE_CHF / 4 / 256;                                                  \
+    f32x4 pipe_st[PIPE_NF4];                                                                      \
+    ChunkSeq<NT_, false, TS_> pipe_seq;                                                           \
     int pipe_n = 0, pipe_total = 0;
 #define PIPE_LOAD() stage_load<PIPE_NF4>(pipe_st, reinterpret_cast<const f32x4 *>(pipe_seq.next(d)), tid)
 #define PIPE_COMMIT(buf_) stage_store<PIPE_NF4>(pipe_st, reinterpret_cast<f32x4 *>(wl + (buf_) * PIPE_CHF), tid)
@@ -1026,10 +1041,52 @@ __device__ __forceinline__ f32x16 gemm_tile_b3(const float *wl, const XSplit &x,
     }
     return acc;
 }
+// N-piece forms (forward kernel): NP = 2 is the above; NP = 3 splits a value into three bf16 pieces that sum to it
+// EXACTLY (3 x 8 significant bits = the fp32 significand) and keeps the six products whose weight is above 2^-24 of the
+// leading one -- fp32-level accuracy (the dropped terms are of the size of one fp32 rounding) at 6 x 32 instead of
+// 16 x 64 MFMA cycles per 16-wide step.
+template <int NP>
+struct XSplitN {
+    bf16x8 p[NP][2];
+};
+template <int NP>
+__device__ __forceinline__ void split_tile_n(const float (&v)[16], XSplitN<NP> &x)
+{
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float f = v[8 * st + j];
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                const __bf16 b = (__bf16)f;
+                x.p[q][st][j] = b;
+                f -= (float)b;
+            }
+        }
+}
+template <int NP>
+__device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP> &x, f32x16 acc, int lane)
+{
+    const bf16x8 *w = reinterpret_cast<const bf16x8 *>(wl);
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        bf16x8 wp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) wp[q] = w[(NP * st + q) * 64 + lane];
+#pragma unroll
+        for (int sum = NP - 1; sum >= 0; sum--)      // smallest products first
+#pragma unroll
+            for (int i = 0; i <= sum; i++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[i], x.p[sum - i][st], acc, 0, 0, 0);
+    }
+    return acc;
+}
 
-template <int NT>
+template <int NT, int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_forward_b3_kernel(DeformDev d)
 {
+    constexpr int TS = NP * 512;   // floats per weight tile in the chunk
     extern __shared__ float wl[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1050,7 +1107,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (has_tail) { int e = b % n_en; for (int k = 0; k < NHEAD; k++) if (d.enabled[k] && e-- == 0) tail_k = k; }
     const int tail_bi = d.full_rounds * G + (n_en ? b / n_en : 0);
     (void)n_bi;
-    ED3_CHUNK_PIPE(NT, false)
+    ED3_CHUNK_PIPE_TS(NT, TS)
     PIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
     for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
         const int bi = (it < my_full) ? b + it * G : tail_bi;
@@ -1073,27 +1130,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         float eb[1][16];
         load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
-        XSplit ebs;
-        split_tile(eb[0], ebs);
+        XSplitN<NP> ebs;
+        split_tile_n<NP>(eb[0], ebs);
 #pragma unroll 1
         for (int s = 0; s < 2; s++) {
             if (d.use_stage[s]) {
                 const float *fr = d.frag[s];
                 unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
-                XSplit as[NT];
+                XSplitN<NP> as[NT];
                 {
                     const float *wb = PIPE_CUR();
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
                         f32x4 bv[4];
                         load_bias4(bv, fr + d.fl.HB, nt, h);
-                        const f32x16 acc = gemm_tile_b3(wb + nt * 1024, ebs, zero_acc(), lane);
+                        const f32x16 acc = gemm_tile_bn<NP>(wb + nt * TS, ebs, zero_acc(), lane);
                         float av[16];
 #pragma unroll
                         for (int r = 0; r < 16; r++) av[r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                         if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, av);
                         if (d.keep) mka |= (unsigned long long)mask16(av) << (16 * nt);
-                        split_tile(av, as[nt]);
+                        split_tile_n<NP>(av, as[nt]);
                     }
                     PIPE_ADVANCE();
                 }
@@ -1116,13 +1173,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
                             f32x16 acc = zero_acc();
 #pragma unroll
-                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_b3(wb + kt * 1024, as[kt], acc, lane);
+                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
                             float z[1][16];
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                             if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
-                            const float *f3 = wb + NT * 1024 + 32 * h + (lane & 3);
+                            const float *f3 = wb + NT * TS + 32 * h + (lane & 3);
 #pragma unroll
                             for (int kk = 0; kk < 16; kk++)
                                 yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
@@ -1151,16 +1208,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
                             f32x16 acc = zero_acc();
 #pragma unroll
-                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_b3(wb + kt * 1024, as[kt], acc, lane);
+                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
                             float z[1][16];
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                             if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
-                            XSplit zs;
-                            split_tile(z[0], zs);
-                            y[0] = gemm_tile_b3(wb + NT * 1024, zs, y[0], lane);
-                            if (nout > 1) y[1] = gemm_tile_b3(wb + (NT + 1) * 1024, zs, y[1], lane);
+                            XSplitN<NP> zs;
+                            split_tile_n<NP>(z[0], zs);
+                            y[0] = gemm_tile_bn<NP>(wb + NT * TS, zs, y[0], lane);
+                            if (nout > 1) y[1] = gemm_tile_bn<NP>(wb + (NT + 1) * TS, zs, y[1], lane);
                             PIPE_ADVANCE();
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
@@ -2742,6 +2799,14 @@ static bool use_b3(const ed3dgs_deform_cfg *c)
 {
     return getenv("ED3DGS_DEFORM_BF16X3") && c->E == 32 && c->W <= 128 && !getenv("ED3DGS_DEFORM_NO_PIPE");
 }
+// bf16 pieces per value in the forward: 0 = exact-fp32 MFMA kernels, 2 = three products (ED3DGS_DEFORM_BF16X3),
+// 3 = six products, fp32-level accuracy (ED3DGS_DEFORM_BF16X6)
+static int fwd_pieces(const ed3dgs_deform_cfg *c)
+{
+    if (c->E != 32 || c->W > 128 || getenv("ED3DGS_DEFORM_NO_PIPE")) return 0;
+    if (getenv("ED3DGS_DEFORM_BF16X6")) return 3;
+    return getenv("ED3DGS_DEFORM_BF16X3") ? 2 : 0;
+}
 
 static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
                      const Workspace &w, bool bwd, hipStream_t s, bool kept = false)
@@ -2767,7 +2832,10 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     hipLaunchKernelGGL(deform_frag_kernel, dim3((unsigned)((nelem + 255) / 256), 2), dim3(256), 0, s, fa);
     if (c->E == 32 && c->W <= 128) {
         const size_t nch = (size_t)fl.n_chunks * fl.ch_floats;
-        if (!bwd && use_b3(c)) hipLaunchKernelGGL(deform_chunk_b3_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+        const int np = bwd ? 0 : fwd_pieces(c);
+        const size_t nch3 = (size_t)fl.n_chunks * (((size_t)(fa.NT + OTMAX) * 1536 + 1023) & ~(size_t)1023);
+        if (np == 3) hipLaunchKernelGGL(deform_chunk_b3_kernel<3>, dim3((unsigned)((nch3 + 255) / 256), 2), dim3(256), 0, s, fa);
+        else if (np == 2) hipLaunchKernelGGL(deform_chunk_b3_kernel<2>, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
         else hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
         if (bwd && kept && use_b3(c))   // the kept-activation data gradient reads its transposed tiles in the b3 format
             hipLaunchKernelGGL(deform_chunk_b3_bwd_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
@@ -2845,8 +2913,16 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
                 for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k];
                 d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
                 d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G && !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
-                if (use_b3(cfg)) hipLaunchKernelGGL((deform_forward_b3_kernel<N>), dim3(G), dim3(256), lds, s, d);
-                else hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                const int np = fwd_pieces(cfg);
+                if (np == 3) {
+                    const size_t lds3 = (size_t)2 * ((((size_t)N + OTMAX) * 1536 + 1023) & ~(size_t)1023) * sizeof(float);   // 1536-float tiles
+                    if (!check_hip(hipFuncSetAttribute((const void *)deform_forward_b3_kernel<N, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3), "set LDS size")) return;
+                    hipLaunchKernelGGL((deform_forward_b3_kernel<N, 3>), dim3(G), dim3(256), lds3, s, d);
+                } else if (np == 2) {
+                    hipLaunchKernelGGL((deform_forward_b3_kernel<N, 2>), dim3(G), dim3(256), lds, s, d);
+                } else {
+                    hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                }
                 return;
             }
         }

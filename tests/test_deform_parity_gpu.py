@@ -52,13 +52,15 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("b3", [False, True], ids=["fp32", "split-bf16"])
+@pytest.mark.parametrize("b3", [False, True, 6], ids=["fp32", "split-bf16", "split-bf16x6-forward"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
 def test_golden_values_and_grads(path, b3, monkeypatch):
     """Against the reference's own outputs; b3 = the opt-in split-bf16 MFMA kernels (ED3DGS_DEFORM_BF16X3=1), held to the
-    same 1e-4."""
+    same 1e-4; 6 = the experimental three-piece / six-product forward (ED3DGS_DEFORM_BF16X6=1, fp32-level accuracy)."""
     _need_gpu()
-    if b3:
+    if b3 == 6:
+        monkeypatch.setenv("ED3DGS_DEFORM_BF16X6", "1")
+    elif b3:
         monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
     z, a = _load(path)
     if int(z["cfg_D"]) > 1:
