@@ -1128,10 +1128,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
             csh[4 * cc] = v.x; csh[4 * cc + 1] = v.y; csh[4 * cc + 2] = v.z; csh[4 * cc + 3] = v.w;
         }
-        float eb[1][16];
-        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
-        XSplitN<NP> ebs;
-        split_tile_n<NP>(eb[0], ebs);
 #pragma unroll 1
         for (int s = 0; s < 2; s++) {
             if (d.use_stage[s]) {
@@ -1139,6 +1135,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
                 XSplitN<NP> as[NT];
                 {
+                    // the embedding tile is re-read per stage (L2) rather than held split across the head loops
+                    float eb[1][16];
+                    load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+                    XSplitN<NP> ebs;
+                    split_tile_n<NP>(eb[0], ebs);
                     const float *wb = PIPE_CUR();
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
