@@ -786,6 +786,35 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
     f32x4 pipe_st[PIPE_NF4];                                                                      \
     ChunkSeq<NT_, false, TS_> pipe_seq;                                                           \
     int pipe_n = 0, pipe_total = 0;
+// LDS-DMA variant (deform_forward_b3_kernel): the chunk goes global -> LDS with no staging registers; one
+// global_load_lds_dwordx4 moves a wave's 64 x 16 contiguous bytes.  Two LDS buffers: chunk n+2 is issued into the buffer
+// chunk n has just been read from, right after the barrier (whose fence drains the DMA of chunk n+1).
+#define ED3_GPIPE(NT_, TS_)                                                                        \
+    constexpr int PIPE_CHF = (((NT_) + OTMAX) * (TS_) + 1023) & ~1023;                             \
+    constexpr int PIPE_NI = PIPE_CHF / 1024;                                                       \
+    ChunkSeq<NT_, false, TS_> pipe_seq;                                                           \
+    int pipe_n = 0, pipe_total = 0;
+#define GPIPE_ISSUE(buf_)                                                                          \
+    do {                                                                                           \
+        const float *gsrc_ = pipe_seq.next(d);                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < PIPE_NI; i_++)                                     \
+            __builtin_amdgcn_global_load_lds(                                                      \
+                (const __attribute__((address_space(1))) void *)(gsrc_ + (i_ * 4 + wave) * 256 + lane * 4), \
+                (__attribute__((address_space(3))) void *)(wl + (buf_) * PIPE_CHF + (i_ * 4 + wave) * 256), 16, 0, 0); \
+    } while (0)
+#define GPIPE_START(total_, ...)                                                                   \
+    do {                                                                                           \
+        pipe_seq.init(d, ##__VA_ARGS__); pipe_n = 0; pipe_total = (total_);                        \
+        if (pipe_total > 0) GPIPE_ISSUE(0);                                                        \
+        __syncthreads();                                                                           \
+        if (pipe_total > 1) GPIPE_ISSUE(1);                                                        \
+    } while (0)
+#define GPIPE_ADVANCE()                                                                            \
+    do {                                                                                           \
+        __syncthreads();                                                                           \
+        if (pipe_n + 2 < pipe_total) GPIPE_ISSUE(pipe_n & 1);                                      \
+        pipe_n++;                                                                                  \
+    } while (0)
 #define PIPE_LOAD() stage_load<PIPE_NF4>(pipe_st, reinterpret_cast<const f32x4 *>(pipe_seq.next(d)), tid)
 #define PIPE_COMMIT(buf_) stage_store<PIPE_NF4>(pipe_st, reinterpret_cast<f32x4 *>(wl + (buf_) * PIPE_CHF), tid)
 #define PIPE_CUR() (wl + (pipe_n & 1) * PIPE_CHF)
@@ -1074,11 +1103,16 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
         bf16x8 wp[NP];
 #pragma unroll
         for (int q = 0; q < NP; q++) wp[q] = w[(NP * st + q) * 64 + lane];
+        // NP = 2: the three products with i + j <= 1.  NP = 3: every product except the last piece times the last piece
+        // (2^-32 of the leading one): eight products, each exact in fp32 -- the sum of piece products is then w x to
+        // 2^-32, i.e. MORE exact than the single rounding of an fp32 multiply; accumulation is fp32 either way.
+        constexpr int SMAX = NP == 2 ? 1 : 3;
 #pragma unroll
-        for (int sum = NP - 1; sum >= 0; sum--)      // smallest products first
+        for (int sum = SMAX; sum >= 0; sum--)        // smallest products first
 #pragma unroll
-            for (int i = 0; i <= sum; i++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[i], x.p[sum - i][st], acc, 0, 0, 0);
+            for (int i = 0; i < NP; i++)
+                if (sum - i >= 0 && sum - i < NP)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[i], x.p[sum - i][st], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -1107,8 +1141,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (has_tail) { int e = b % n_en; for (int k = 0; k < NHEAD; k++) if (d.enabled[k] && e-- == 0) tail_k = k; }
     const int tail_bi = d.full_rounds * G + (n_en ? b / n_en : 0);
     (void)n_bi;
-    ED3_CHUNK_PIPE_TS(NT, TS)
-    PIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
+    ED3_GPIPE(NT, TS)
+    GPIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
     for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
         const int bi = (it < my_full) ? b + it * G : tail_bi;
         const int konly = (it < my_full) ? -1 : tail_k;
@@ -1153,7 +1187,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         if (d.keep) mka |= (unsigned long long)mask16(av) << (16 * nt);
                         split_tile_n<NP>(av, as[nt]);
                     }
-                    PIPE_ADVANCE();
+                    GPIPE_ADVANCE();
                 }
                 if (d.keep && gvalid) d.MK[s][((size_t)g) * 2 + h] = mka;
                 for (int k = 0; k < NHEAD; k++) {
@@ -1184,7 +1218,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                             for (int kk = 0; kk < 16; kk++)
                                 yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
-                            PIPE_ADVANCE();
+                            GPIPE_ADVANCE();
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
@@ -1219,7 +1253,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             split_tile_n<NP>(z[0], zs);
                             y[0] = gemm_tile_bn<NP>(wb + NT * TS, zs, y[0], lane);
                             if (nout > 1) y[1] = gemm_tile_bn<NP>(wb + (NT + 1) * TS, zs, y[1], lane);
-                            PIPE_ADVANCE();
+                            GPIPE_ADVANCE();
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         {   // head output bias, after the contraction (see load_bias4)
