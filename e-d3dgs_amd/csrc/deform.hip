@@ -428,6 +428,59 @@ __global__ void __launch_bounds__(256) deform_chunk_b3_bwd_kernel(FragArgs a)
     a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
 }
 
+// chunks of the kept-activation data gradient in the N-piece format, compact: chunk (k, nt) = [F3T (OTMAX tiles) | F2T (NT
+// tiles)], last chunk = F1T (NT tiles); tiles of NP * 512 floats as in deform_chunk_b3_kernel; narrow heads' F3T in the
+// fp32 fragment layout.
+template <int NP>
+__global__ void __launch_bounds__(256) deform_chunk_kept_kernel(FragArgs a)
+{
+    const int s = blockIdx.y;
+    if (!a.use_stage[s]) return;
+    constexpr int TS = NP * 512;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
+    const int CHK = ((NT + OTMAX) * TS + 1023) & ~1023, NCH = NHEAD * NT + 1;
+    if (idx >= (size_t)NCH * CHK) return;
+    const int cidx = (int)(idx / CHK), o = (int)(idx % CHK);
+    const int t = o / TS, f = o % TS;
+    const float *p = a.params[s];
+    const bool last = cidx == NCH - 1;
+    if (t >= NT + OTMAX || (last && t >= NT)) return;
+    const int k = cidx / NT, nt = cidx % NT;
+    if (!last && t < OTMAX && k < 4) {   // narrow head: F3T in the fp32 fragment layout
+        if (f >= 1024) return;
+        const int lane = f & 63, kk = (f >> 6) & 15, fs = fslot(kk, lane >> 5), cl = lane & 31;
+        const int row = t * 32 + fs;
+        a.frag[s][a.fl.CH + idx] = row < head_nk(k, a.n_sh) ? p[a.pl.W3[k] + (size_t)row * W + nt * 32 + cl] : 0.f;
+        return;
+    }
+    const int blk = f >> 8, ks = blk / NP, part = blk % NP, lane = (f >> 2) & 63, j0 = 2 * (f & 3);
+    const int r = lane & 31, h = lane >> 5;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int j = j0 + e, kin = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float w = 0.f;
+        if (last) {                            // F1T[kt = t]: A[i = e][k = hidden feature]
+            w = p[a.pl.W1 + (size_t)(t * 32 + kin) * ld1 + a.TD + r];
+        } else if (t < OTMAX) {                // F3T[k = 4][it = nt][ot = t]: A[i = hidden feature][k = output]
+            const int row = t * 32 + kin;
+            if (row < head_nk(k, a.n_sh)) w = p[a.pl.W3[k] + (size_t)row * W + nt * 32 + r];
+        } else {                               // F2T[k][it = t - OTMAX][ot = nt]
+            w = p[a.pl.W2[k] + (size_t)(nt * 32 + kin) * W + (t - OTMAX) * 32 + r];
+        }
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            v = bf16_rne(w);
+            if (q == part) break;
+            w -= __uint_as_float(v << 16);
+        }
+        packed |= v << (16 * e);
+    }
+    a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // MFMA helpers
 // ------------------------------------------------------------------------------------------------------------
@@ -1444,7 +1497,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // g_hid = g_a masked by a > 0 (stored for dW1) and g_emb = W1[:, TD:]^T g_hid.  Weight chunks are the [F3T | F2T]
 // tails of the backward chunk layout (frag_layout), then the transposed trunk.
 // ------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int TS = 0>   // TS = 0: the tails of the fp32 backward chunks; TS > 0: the compact N-piece layout (deform_chunk_kept_kernel)
 struct ChunkSeqKept {
     int s, e, nt;   // e = index into the enabled heads; e == n_en: transposed trunk chunk
     int n_en;
@@ -1462,7 +1515,13 @@ struct ChunkSeqKept {
         const int n_chunks = 1 + NHEAD * NT + 1;
         const size_t chb = (size_t)(2 * NT + OTMAX) * 1024;
         const float *base = d.frag[s] + d.fl.CH;
-        const float *p = (e < n_en) ? base + (size_t)(1 + (int)(en_pack >> (4 * e) & 15u) * NT + nt) * chb + NT * 1024 : base + (size_t)(n_chunks - 1) * chb;
+        const float *p;
+        if (TS == 0) {
+            p = (e < n_en) ? base + (size_t)(1 + (int)(en_pack >> (4 * e) & 15u) * NT + nt) * chb + NT * 1024 : base + (size_t)(n_chunks - 1) * chb;
+        } else {
+            const size_t chk = (size_t)((((NT + OTMAX) * TS) + 1023) & ~1023);
+            p = base + (size_t)((e < n_en) ? (int)(en_pack >> (4 * e) & 15u) * NT + nt : NHEAD * NT) * chk;
+        }
         if (e < n_en && nt + 1 < NT) { nt++; return p; }
         nt = 0;
         if (e < n_en) { e++; return p; }
@@ -1747,6 +1806,149 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 ge = gemm_tile_b3(PIPE_CUR() + nt * 1024, ghs, ge, lane);
             }
             PIPE_ADVANCE();
+        }
+        if (gvalid) {
+            if (sonly >= 0) {   // tail unit: one of two addends into rows the host zeroed
+#pragma unroll
+                for (int r = 0; r < 16; r++) atomicAdd(d.g_emb + (size_t)g * d.E + (r & 3) + 8 * (r >> 2) + 4 * h, ge[r]);
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = ge[r];
+                store_tile_rows(d.g_emb, d.E, g, 0, h, v);
+            }
+        }
+    }
+}
+
+// N-piece form of the above with LDS-DMA staging and the compact chunk layout (NP = 3: eight exact products per step)
+template <int NT, int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_dgrad_kept_bn_kernel(DeformDev d)
+{
+    constexpr int TS = NP * 512;
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_bi = (d.P + 127) / 128;
+    const int shw = 3 * d.n_sh;
+    const bool both = d.use_stage[0] && d.use_stage[1];
+    int n_en = 0;
+    uint32_t en_pack = 0;
+    for (int k = 0; k < NHEAD; k++) if (d.enabled[k]) en_pack |= (uint32_t)k << (4 * n_en++);
+#define EN_K(e_) ((int)(en_pack >> (4 * (e_)) & 15u))
+    const int per_iter = (d.use_stage[0] + d.use_stage[1]) * (n_en * NT + 1);
+    // block schedule as in deform_forward_pipe_kernel; here a TAIL UNIT is (group, stage): the two stages of a group
+    // are independent up to dL/d embedding, which the two units add atomically into zeroed rows (two addends: the
+    // result does not depend on their order)
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
+    const bool has_tail = d.tail_split && b < d.rem_units * 2;
+    const int tail_s = has_tail ? (b & 1) : -1;
+    const int tail_bi = d.full_rounds * G + (b >> 1);
+    (void)n_bi;
+    const size_t PW = (size_t)d.P * d.W;
+    constexpr int PIPE_CHF = (((NT) + OTMAX) * TS + 1023) & ~1023;
+    constexpr int PIPE_NI = PIPE_CHF / 1024;
+    ChunkSeqKept<NT, TS> pipe_seq;
+    int pipe_n = 0, pipe_total = 0;
+    GPIPE_START(my_full * per_iter + (has_tail ? n_en * NT + 1 : 0), my_full, tail_s);
+    for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
+        const int bi = (it < my_full) ? b + it * G : tail_bi;
+        const int sonly = (it < my_full) ? -1 : tail_s;
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        f32x16 ge;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ge[r] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (!d.use_stage[s] || (sonly >= 0 && s != sonly)) continue;
+            const bool add_sub = (s == 0);
+            const bool add_out = (s == 1) || both || !d.use_stage[1];
+            f32x16 ga[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
+            // the kept sign masks (16 bytes per Gaussian, head and stage) stand in for the relu tiles themselves
+            const unsigned long long *mk = d.MK[s] + (size_t)g * 2 + h;
+            const unsigned long long mka = mk[0];
+            unsigned long long mkn = n_en > 0 ? mk[(size_t)(1 + EN_K(0)) * d.P * 2] : 0ull;
+#pragma unroll 1
+            for (int e = 0; e < n_en; e++) {
+                const int k = EN_K(e);
+                const unsigned long long mkz = mkn;
+                if (e + 1 < n_en) mkn = mk[(size_t)(1 + EN_K(e + 1)) * d.P * 2];   // next head's mask flies under this head's MFMAs
+                const float hc = d.hc[k];
+                const int nk = d.nk[k];
+                float gy[OTMAX][16];
+#pragma unroll
+                for (int ot = 0; ot < OTMAX; ot++)
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
+                if (k < 4) {
+                    if (h == 0) {
+                        for (int j = 0; j < nk; j++) {
+                            float v = 0.f;
+                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
+                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
+                            gy[0][j] = v * hc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) {
+                        const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                        float4 v = make_float4(0, 0, 0, 0);
+                        if (feat < shw) {
+                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                        }
+                        const int ot = cc >> 2, kk0 = 4 * (cc & 3);
+                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                    }
+                }
+                XSplitN<NP> gys[OTMAX];
+                if (k >= 4) {
+#pragma unroll
+                    for (int ot = 0; ot < OTMAX; ot++) split_tile_n<NP>(gy[ot], gys[ot]);
+                }
+#pragma unroll 1
+                for (int nt = 0; nt < NT; nt++) {
+                    const float *wb = PIPE_CUR();
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    if (k < 4) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++) acc = gemm_tile_bn<NP>(wb + ot * TS, gys[ot], acc, lane);
+                    }
+                    float z[1][16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[0][r] = (mkz >> (16 * nt + r)) & 1ull ? acc[r] : 0.f;
+                    XSplitN<NP> zs;
+                    split_tile_n<NP>(z[0], zs);
+#pragma unroll
+                    for (int i2 = 0; i2 < NT; i2++) ga[i2] = gemm_tile_bn<NP>(wb + (OTMAX + i2) * TS, zs, ga[i2], lane);
+                    GPIPE_ADVANCE();
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                float gh[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) gh[r] = (mka >> (16 * nt + r)) & 1ull ? ga[nt][r] : 0.f;
+                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh);
+                XSplitN<NP> ghs;
+                split_tile_n<NP>(gh, ghs);
+                ge = gemm_tile_bn<NP>(PIPE_CUR() + nt * TS, ghs, ge, lane);
+            }
+            GPIPE_ADVANCE();
         }
         if (gvalid) {
             if (sonly >= 0) {   // tail unit: one of two addends into rows the host zeroed
@@ -2874,6 +3076,10 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
         else hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
         if (bwd && kept && use_b3(c))   // the kept-activation data gradient reads its transposed tiles in the b3 format
             hipLaunchKernelGGL(deform_chunk_b3_bwd_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+        if (bwd && kept && fwd_pieces(c) == 3) {   // ... or, three-piece mode, its own compact chunks
+            const size_t nk3 = (size_t)(NHEAD * fa.NT + 1) * ((((size_t)fa.NT + OTMAX) * 1536 + 1023) & ~(size_t)1023);
+            hipLaunchKernelGGL(deform_chunk_kept_kernel<3>, dim3((unsigned)((nk3 + 255) / 256), 2), dim3(256), 0, s, fa);
+        }
     }
     hipLaunchKernelGGL(deform_frame_kernel, dim3(2), dim3(256), 0, s, fr);
     return check_hip(hipGetLastError(), "deform prep");
@@ -3060,7 +3266,11 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                         okp = check_hip(hipMemsetAsync(g_embedding + r0 * cfg->E, 0, ((size_t)cfg->P - r0) * cfg->E * sizeof(float), s), "memset g_emb tail");
                         if (!okp) return;
                     }
-                    if (use_b3(cfg)) hipLaunchKernelGGL((deform_dgrad_kept_b3_kernel<N>), dim3(G), dim3(256), lds, s, d);
+                    if (fwd_pieces(cfg) == 3) {
+                        const size_t lds3 = (size_t)2 * ((((size_t)N + OTMAX) * 1536 + 1023) & ~(size_t)1023) * sizeof(float);
+                        okp = check_hip(hipFuncSetAttribute((const void *)deform_dgrad_kept_bn_kernel<N, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3), "set LDS size");
+                        if (okp) hipLaunchKernelGGL((deform_dgrad_kept_bn_kernel<N, 3>), dim3(G), dim3(256), lds3, s, d);
+                    } else if (use_b3(cfg)) hipLaunchKernelGGL((deform_dgrad_kept_b3_kernel<N>), dim3(G), dim3(256), lds, s, d);
                     else hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(G), dim3(256), lds, s, d);
                     return;
                 }
