@@ -1131,21 +1131,53 @@ template <int NP>
 struct XSplitN {
     bf16x8 p[NP][2];
 };
+// Splitting by TRUNCATION: piece 0 = the high 16 bits of x (an exact bf16), r = x - piece 0 is exact in fp32 and has at
+// most 16 significant bits, piece 1 = its high 16 bits, piece 2 = what is left (<= 8 significant bits: already a bf16).
+// x = p0 + p1 + p2 exactly, with 4 VALU operations per value (and, sub, and, sub) plus one v_perm_b32 per piece and
+// pair of values to pack the high halves -- against 9 for the round-to-nearest chain.  Two pieces: the second is the
+// rounded residual.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack_hi16(float lo_elem, float hi_elem)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+template <int NP>
+__device__ __forceinline__ void split8_n(const float (&v)[8], bf16x8 (&p)[NP])
+{
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        r1[j] = v[j] - __uint_as_float(__float_as_uint(v[j]) & 0xFFFF0000u);
+        if (NP == 3) r2[j] = r1[j] - __uint_as_float(__float_as_uint(r1[j]) & 0xFFFF0000u);
+    }
+    u32x4 w0, w1, w2;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        w0[jj] = pack_hi16(v[2 * jj], v[2 * jj + 1]);
+        if (NP == 3) { w1[jj] = pack_hi16(r1[2 * jj], r1[2 * jj + 1]); w2[jj] = pack_hi16(r2[2 * jj], r2[2 * jj + 1]); }
+    }
+    p[0] = __builtin_bit_cast(bf16x8, w0);
+    if constexpr (NP == 3) {
+        p[1] = __builtin_bit_cast(bf16x8, w1);
+        p[2] = __builtin_bit_cast(bf16x8, w2);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[1][j] = (__bf16)r1[j];
+    }
+}
 template <int NP>
 __device__ __forceinline__ void split_tile_n(const float (&v)[16], XSplitN<NP> &x)
 {
 #pragma unroll
-    for (int st = 0; st < 2; st++)
+    for (int st = 0; st < 2; st++) {
+        float v8[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float f = v[8 * st + j];
+        for (int j = 0; j < 8; j++) v8[j] = v[8 * st + j];
+        bf16x8 p[NP];
+        split8_n<NP>(v8, p);
 #pragma unroll
-            for (int q = 0; q < NP; q++) {
-                const __bf16 b = (__bf16)f;
-                x.p[q][st][j] = b;
-                f -= (float)b;
-            }
-        }
+        for (int q = 0; q < NP; q++) x.p[q][st] = p[q];
+    }
 }
 template <int NP>
 __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP> &x, f32x16 acc, int lane)
@@ -2769,6 +2801,170 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
     if (DW3 && tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Narrow-head weight gradients in the N-piece form (NP = 3: eight exact bf16 piece products per 16-wide step, fp32-level
+// accuracy).  Same decomposition as head_wgrad_body<false, ...> -- block = (stage, head, range of Gaussians), wave = 2 x 2
+// patch of dW2, g_z re-formed on chip with the Gaussian on the register index -- with the slabs of relu(z) and a brought
+// in by LDS-DMA into a DOUBLE buffer (no staging registers, one barrier per slab): the next slab's DMA is issued before
+// the current slab's MFMAs and drained by the barrier's fence.  g_y (<= 4 floats per Gaussian) still goes through
+// registers (it is scaled and summed on the way).
+// ------------------------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_bn(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16 acc)
+{
+    constexpr int SMAX = NP == 2 ? 1 : 3;
+#pragma unroll
+    for (int sum = SMAX; sum >= 0; sum--)
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            if (sum - i >= 0 && sum - i < NP) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[sum - i], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_narrow_bn_kernel(HeadWgradArgs a)
+{
+    extern __shared__ float hj_lds[];
+    constexpr int LDG = 33, SLAB = 32 * HJ_W;                 // floats per slab
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    const HeadJob &J = a.job[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pmi = wave >> 1, pni = wave & 1;
+    const int nk = J.nk, P = a.P;
+    // LDS: [buf][z slab | a slab], then [buf][g_y slab]
+    float *gsb = hj_lds + 4 * SLAB;
+    const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int p0 = split * chunk, p1 = min(P, p0 + chunk);
+    if (p0 >= p1) return;
+    const int nslab = (p1 - p0 + 31) / 32;
+    for (int e = tid; e < 2 * 32 * LDG; e += 256) gsb[e] = 0.f;   // pad columns stay zero
+    float w3f[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int k = 2 * kk + h;
+            w3f[t][kk] = (k < nk) ? J.W3[(size_t)k * HJ_W + (2 * pmi + t) * 32 + c] : 0.f;
+        }
+    f32x16 acc[2][2];
+    f32x4 acc3n = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
+    float bsum2[2] = {0.f, 0.f}, bsum3 = 0.f;
+    const bool has_g2 = J.G2 != nullptr;
+    const int gcount = 32 * nk;
+    float gv = 0.f, g2v = 0.f;
+    // slab rows [r0, r0 + 32) of relu(z) and a: 2 x 16 KB = 32 DMA instructions of 1 KB, 8 per wave; rows past the range
+    // re-read the last row (their g_y is zero)
+    auto dma = [&](int slab, int buf) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int piece = i * 4 + wave;                    // 1-KB piece = 2 rows of 128 floats
+            const int row = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
+            const size_t o = (size_t)min(r0 + row, p1 - 1) * HJ_W + col;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.ZR + o),
+                                             (__attribute__((address_space(3))) void *)(hj_lds + buf * 2 * SLAB + piece * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.A + o),
+                                             (__attribute__((address_space(3))) void *)(hj_lds + buf * 2 * SLAB + SLAB + piece * 256), 16, 0, 0);
+        }
+    };
+    auto load_g = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+        const size_t o = (size_t)r0 * nk + min(tid, (p1 - r0) * nk - 1);
+        gv = J.G[o];
+        if (has_g2) g2v = J.G2[o];
+    };
+    auto store_g = [&](int slab, int buf) {
+        const int r0 = p0 + slab * 32;
+        if (tid < gcount) {
+            const int r = tid / nk, cc = tid - r * nk;
+            float v = gv;
+            if (has_g2) v += g2v;
+            gsb[buf * 32 * LDG + r * LDG + cc] = (r0 + r < p1) ? v * J.gscale : 0.f;
+        }
+    };
+    __syncthreads();
+    dma(0, 0);
+    load_g(0);
+    store_g(0, 0);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; slab++) {
+        const int buf = slab & 1;
+        const float *zs = hj_lds + buf * 2 * SLAB, *as = zs + SLAB, *gs = gsb + buf * 32 * LDG;
+        if (slab + 1 < nslab) { dma(slab + 1, buf ^ 1); load_g(slab + 1); }
+        XSplitN<NP> gzs[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            f32x16 dd;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dd[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) dd = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], w3f[t][kk], dd, 0, 0, 0);
+            float gz[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                gz[r] = zs[row * HJ_W + (2 * pmi + t) * 32 + c] > 0.f ? dd[r] : 0.f;
+                bsum2[t] += gz[r];
+            }
+            split_tile_n<NP>(gz, gzs[t]);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            bf16x8 ga0[NP], ga1[NP];
+#pragma unroll
+            for (int q = 0; q < NP; q++) { ga0[q] = gzs[0].p[q][st]; ga1[q] = gzs[1].p[q][st]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v8[j] = as[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * HJ_W + (2 * pni + u) * 32 + c];
+                bf16x8 bp[NP];
+                split8_n<NP>(v8, bp);
+                acc[0][u] = mfma_bn<NP>(ga0, bp, acc[0][u]);
+                acc[1][u] = mfma_bn<NP>(ga1, bp, acc[1][u]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const int row = 2 * kk + h;
+            acc3n = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[row * LDG + (lane & 3)], zs[row * HJ_W + wave * 32 + c], acc3n, 0, 0, 0);
+        }
+        if (tid < nk) {
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) bsum3 += gs[r * LDG + tid];
+        }
+        if (slab + 1 < nslab) store_g(slab + 1, buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mi = (2 * pmi + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(J.dW2 + (size_t)mi * HJ_W + (2 * pni + u) * 32 + c, acc[t][u][r]);
+            }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float v = acc3n[i] + __shfl_xor(acc3n[i], 32);
+        if (h == 0 && i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, v);
+    }
+    if (pni == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const float v = bsum2[t] + __shfl_xor(bsum2[t], 32);
+            if (h == 0) atomicAdd(J.db2 + (2 * pmi + t) * 32 + c, v);
+        }
+    }
+    if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
+}
+
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
 template <bool WIDE, bool B3, bool DW3 = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_kernel(HeadWgradArgs a)
@@ -3390,7 +3586,11 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 hipLaunchKernelGGL((deform_head_wgrad_kernel<true, false>), dim3(nblk), dim3(256), lds, s, ha);
             }
         } else {
-            if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
+            if (fwd_pieces(cfg) == 3) {
+                const size_t ldsn = (size_t)(4 * 32 * HJ_W + 2 * 32 * 33) * sizeof(float);   // two (z, a) slab pairs + two g_y slabs
+                if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_narrow_bn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn), "set LDS size")) return ED3DGS_ERR_HIP;
+                hipLaunchKernelGGL(deform_head_wgrad_narrow_bn_kernel<3>, dim3(nblk), dim3(256), ldsn, s, ha);
+            } else if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
             else hipLaunchKernelGGL((deform_head_wgrad_kernel<false, false>), dim3(nblk), dim3(256), lds, s, ha);
         }
     }
