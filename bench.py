@@ -28,6 +28,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-operand MFMA peak (MI355X_MICROARCH.md, matrix-core table)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
+MODE_VARS = ("ED3DGS_DEFORM_FP32_MFMA", "ED3DGS_DEFORM_BF16X3", "ED3DGS_DEFORM_BF16X6", "ED3DGS_DEFORM_NO_PIPE")
 WORKLOADS = {
     "C3": dict(P=200_000, W=1920, H=1080, cams=8, frames=50, deform=True,
                name="C3: 200k Gaussians, 8 cams x 50 timesteps, 1080p, deform MLP W=128 D=1, depth+normal (FTT)"),
@@ -225,15 +227,16 @@ def main():
     _C.LAST.clear()
 
     # ---- per-kernel table: an instrumented, UNTIMED pass (five event pairs per step cost stream time) ----
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0x1F))
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0xFF))
     for k in range(a.steps):
         step(item_at(k))
     step.drain()
     torch.cuda.synchronize()
-    tab_ms, tab_n = (ctypes.c_double * 5)(), (ctypes.c_int * 5)()
+    NS = 8  # ED3DGS_PROF_SLOTS; slot 4 is the three weight-gradient launches together, 5..7 each of them
+    tab_ms, tab_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(tab_ms, tab_n)
-    tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(5)]
-    dom = max(range(5), key=lambda i: tab_avg[i])
+    tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(NS)]
+    dom = max([i for i in range(NS) if i != 4], key=lambda i: tab_avg[i])   # the dominant single KERNEL
 
     # ---- timed: exactly K steps; events only around the dominant kernel and K7 ----
     torch.cuda.synchronize(); D.barrier()
@@ -245,10 +248,11 @@ def main():
     step.drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
-    slot_ms, slot_n = (ctypes.c_double * 5)(), (ctypes.c_int * 5)()
+    slot_ms, slot_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(slot_ms, slot_n)
-    # K6, K7, deform fwd, deform dgrad, deform wgrad: timed-region events where taken, else the instrumented pass
-    avg_ms = [slot_ms[i] / slot_n[i] if slot_n[i] else tab_avg[i] for i in range(5)]
+    # K6, K7, deform fwd, deform dgrad, deform wgrad (+ its three launches): timed-region events where taken, else the
+    # instrumented pass
+    avg_ms = [slot_ms[i] / slot_n[i] if slot_n[i] else tab_avg[i] for i in range(NS)]
     dt = D.max_over_ranks(dt, device)
 
     log("timed region done: %.3f ms/step" % (dt / a.steps * 1e3))
@@ -262,10 +266,11 @@ def main():
         dt_r = time.perf_counter() - t1
     dt_r = D.max_over_ranks(dt_r, device)
 
-    # ---- extra, not the headline: the same K steps / K renders with the deformation MLP on split-bf16 MFMA ----
-    b3 = None
-    if wl["deform"] and not os.environ.get("ED3DGS_DEFORM_BF16X3"):
-        os.environ["ED3DGS_DEFORM_BF16X3"] = "1"      # read by the library at every call
+    # ---- extras, not the headline: the same K steps / K renders with the deformation MLP in its other two modes ----
+    def other_mode(var, note):
+        if not wl["deform"] or any(os.environ.get(v) for v in MODE_VARS):
+            return None
+        os.environ[var] = "1"      # read by the library at every call
         try:
             for k in range(3):
                 step(item_at(k))
@@ -283,12 +288,20 @@ def main():
                     step(item_at(k), backward=False, coord=True)
                 torch.cuda.synchronize()
                 dt_br = D.max_over_ranks(time.perf_counter() - t3, device)
-            b3 = {"ms_per_step": dt_b / a.steps * 1e3, "value": world * a.steps / dt_b, "render_fps": world * a.steps / dt_br,
-                  "note": "opt-in ED3DGS_DEFORM_BF16X3=1: MLP contractions as three bf16 products with fp32 accumulation "
-                          "(deformation outputs / gradients within 1e-6 / 2e-5 of the fp32 reference values, tolerance 1e-4; "
-                          "DESIGN.md section 2); the headline above runs the exact-fp32 MFMA kernels"}
+            return {"ms_per_step": dt_b / a.steps * 1e3, "value": world * a.steps / dt_b,
+                    "render_fps": world * a.steps / dt_br, "note": note}
         finally:
-            del os.environ["ED3DGS_DEFORM_BF16X3"]
+            del os.environ[var]
+
+    mode = "fp32_mfma" if os.environ.get("ED3DGS_DEFORM_FP32_MFMA") or os.environ.get("ED3DGS_DEFORM_NO_PIPE") else \
+           "bf16x3" if os.environ.get("ED3DGS_DEFORM_BF16X3") and not os.environ.get("ED3DGS_DEFORM_BF16X6") else "exact_split"
+    f32m = other_mode("ED3DGS_DEFORM_FP32_MFMA",
+                      "ED3DGS_DEFORM_FP32_MFMA=1: every MLP contraction on v_mfma_f32_32x32x2_f32 (the round's first kernels; "
+                      "same results as the headline mode to fp32 rounding, DESIGN.md section 2)")
+    b3 = other_mode("ED3DGS_DEFORM_BF16X3",
+                    "opt-in ED3DGS_DEFORM_BF16X3=1: two bf16 pieces per operand, three products, fp32 accumulation "
+                    "(deformation outputs / gradients within 1e-6 / 2e-5 of the fp32 values, tolerance 1e-4; REDUCED "
+                    "precision, never the headline)")
 
     if rank != 0:
         return
@@ -296,14 +309,14 @@ def main():
     mean = lambda v: sum(v) / max(len(v), 1)
     bytes_k7 = 128.0 * mean(reff) + 68.0 * HW + 8.0 * T   # FTT: (g_b + 4a) R_eff + r HW + 8T  
     bytes_k6 = 68.0 * mean(reff) + 56.0 * HW + 8.0 * T
-    k6_ms, k7_ms, dfw_ms, ddg_ms, dwg_ms = avg_ms
+    k6_ms, k7_ms = avg_ms[0], avg_ms[1]
     ach = bytes_k7 / (k7_ms * 1e-3) / 1e9 if k7_ms > 0 else 0.0
     pmc = {}
     prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
-            if pj.get("workload") == a.workload:
+            if pj.get("workload") == a.workload and pj.get("mode", "fp32_mfma") == mode:
                 pmc = pj.get("hbm_bytes_per_launch", {})
         except Exception:
             pmc = {}
@@ -312,19 +325,35 @@ def main():
     from ed3dgs_amd.model import default_hyper
     hy = default_hyper()
     Wn, En = int(hy.net_width), int(hy.gaussian_embedding_dim)
-    macs = 2 * (En * Wn + 5 * Wn * Wn + Wn * (3 + 3 + 4 + 1 + 48)) if wl.get("deform", True) else 0
-    flops = 2.0 * macs * wl["P"]          # per launch: forward == data-gradient == weight-gradient contraction count
-    tf = lambda ms: flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    t6, t7, tfw, tdg, twg = tab_avg
-    kernels = {
-        "_source": "separate instrumented pass of the same %d steps (event pairs around all five kernels), not the timed region" % a.steps,
-        "render_forward_kernel<false,true> (K6)": {"avg_launch_ms": t6, "launches": tab_n[0], "bound": "valu", "GBps_algorithmic": bytes_k6 / (t6 * 1e-3) / 1e9 if t6 > 0 else 0.0},
-        "render_backward_kernel<false,true> (K7)": {"avg_launch_ms": t7, "launches": tab_n[1], "bound": "valu", "GBps_algorithmic": bytes_k7 / (t7 * 1e-3) / 1e9 if t7 > 0 else 0.0},
-        "deform_forward_pipe_kernel<4>": {"avg_launch_ms": tfw, "launches": tab_n[2], "bound": "mfma", "TFLOPs_algorithmic": tf(tfw)},
-        "deform_dgrad_kept_kernel<4>": {"avg_launch_ms": tdg, "launches": tab_n[3], "bound": "mfma", "TFLOPs_algorithmic": tf(tdg),
-                                        "note": "activations kept by the forward launch (3 KB per Gaussian and stage), nothing re-formed"},
-        "deform_head_wgrad_kernel + deform_wgrad_kernel": {"avg_launch_ms": twg, "launches": tab_n[4], "bound": "mfma", "TFLOPs_algorithmic": tf(twg)},
+    dm = wl.get("deform", True)
+    outs = 3 + 3 + 4 + 1 + 48
+    mac_all = 2 * (En * Wn + 5 * Wn * Wn + Wn * outs) if dm else 0          # forward == data gradient, both stages
+    mac_trunk = 2 * En * Wn if dm else 0                                        # dW1
+    mac_wide = 2 * (Wn * Wn + Wn * 48) if dm else 0                             # SH head: dW2 + dW3
+    mac_narrow = 2 * (4 * Wn * Wn + Wn * (outs - 48)) if dm else 0              # the four narrow heads
+    # pieces per operand pair executed on the matrix pipe, per kernel and mode: 8 exact bf16 products (exact_split),
+    # 3 (bf16x3), or 1 f32 product
+    npr = {"exact_split": 8, "bf16x3": 3, "fp32_mfma": 1}[mode]
+    K = {  # slot -> (kernel name, algorithmic MAC per Gaussian, products per MAC, matrix pipe)
+        2: ({"exact_split": "deform_forward_b3_kernel<4,3>", "bf16x3": "deform_forward_b3_kernel<4,2>", "fp32_mfma": "deform_forward_pipe_kernel<4>"}[mode], mac_all, npr),
+        3: ({"exact_split": "deform_dgrad_kept_bn_kernel<4,3>", "bf16x3": "deform_dgrad_kept_b3_kernel<4>", "fp32_mfma": "deform_dgrad_kept_kernel<4>"}[mode], mac_all, npr),
+        5: ("deform_wgrad_kernel (dW1)", mac_trunk, 1),
+        6: ({"exact_split": "deform_head_wgrad_kernel<true,false>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false>"}[mode], mac_wide, 3 if mode == "bf16x3" else 1),
+        7: ({"exact_split": "deform_head_wgrad_narrow_bn_kernel<3>", "bf16x3": "deform_head_wgrad_kernel<false,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false>"}[mode], mac_narrow, npr),
     }
+    tfl = lambda mac, ms: 2.0 * mac * wl["P"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    kernels = {
+        "_source": "separate instrumented pass of the same %d steps (event pairs around every kernel), not the timed region" % a.steps,
+        "_mode": mode,
+        "render_forward_kernel<false,true> (K6)": {"avg_launch_ms": tab_avg[0], "launches": tab_n[0], "bound": "valu", "GBps_algorithmic": bytes_k6 / (tab_avg[0] * 1e-3) / 1e9 if tab_avg[0] > 0 else 0.0},
+        "render_backward_kernel<false,true> (K7)": {"avg_launch_ms": tab_avg[1], "launches": tab_n[1], "bound": "valu", "GBps_algorithmic": bytes_k7 / (tab_avg[1] * 1e-3) / 1e9 if tab_avg[1] > 0 else 0.0},
+    }
+    if dm:
+        for sl, (nm, mac, pr) in K.items():
+            kernels[nm] = {"avg_launch_ms": tab_avg[sl], "launches": tab_n[sl], "bound": "mfma",
+                           "TFLOPs_fp32_equivalent": tfl(mac, tab_avg[sl]),
+                           "matrix_pipe": "bf16 (%d exact piece products per multiply)" % pr if pr > 1 else "f32"}
+        kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                "traffic": pmc.get("render_backward_kernel"),
@@ -332,20 +361,19 @@ def main():
                "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
                        "reported as defined there, next to the pair rate"}
-    if dom >= 2 and macs:
-        name = ["", "", "deform_forward_pipe_kernel<4>", "deform_dgrad_kept_kernel<4>", "deform_head_wgrad_kernel + deform_wgrad_kernel"][dom]
-        roof = {"bound": "mfma", "kernel": name, "achieved": tf(avg_ms[dom]), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": tf(avg_ms[dom]) / MFMA_F32_PEAK_TFLOPS,
-                "traffic": (pmc.get("deform_head_wgrad_kernel", 0) + pmc.get("deform_wgrad_kernel", 0) or None) if dom == 4
-                           else pmc.get(name.split("<")[0].split(" ")[0]),
-                "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
-                "note": "dominant kernel of the step by time; fp32 operands on v_mfma_f32_32x32x2f32 (dense f32 MFMA peak "
-                        "157.3 TFLOP/s); algorithmic flops = 2 * %d MAC per Gaussian" % macs}
-        if dom == 4:
-            roof["note"] += ("; one weight-gradient pass = three back-to-back launches timed by one event pair "
-                             "(deform_wgrad_kernel, deform_head_wgrad_kernel<true>, deform_head_wgrad_kernel<false>: "
-                             "add their rocprofv3 averages); the head kernels also re-form g_z = (g_y W3) * (z > 0) per "
-                             "slab, so they execute ~1.15x this count")
+    if dom >= 2 and dm:
+        nm, mac, pr = K[dom]
+        eq = tfl(mac, avg_ms[dom])
+        peak = MFMA_BF16_PEAK_TFLOPS if pr > 1 else MFMA_F32_PEAK_TFLOPS
+        roof = {"bound": "mfma", "kernel": nm, "achieved": eq * pr, "peak": peak, "unit": "TFLOP/s", "frac": eq * pr / peak,
+                "traffic": pmc.get(nm.split("<")[0].split(" ")[0]),
+                "algorithmic_flops_per_launch": 2.0 * mac * wl["P"], "executed_matrix_flops_per_launch": 2.0 * mac * wl["P"] * pr,
+                "fp32_equivalent_TFLOPs": eq, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
+                "note": ("dominant kernel of the step by time.  Algorithmic flops = 2 * %d MAC per Gaussian (fp32 multiplies); " % mac) +
+                        ("each fp32 multiply runs as %d exact bf16 piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, "
+                         "so `achieved` = executed piece-product flops / launch time against the dense bf16 MFMA peak; "
+                         "fp32_equivalent_TFLOPs is the algorithmic rate (the f32-operand MFMA peak is 157.3)" % pr if pr > 1 else
+                         "fp32 operands on v_mfma_f32_32x32x2_f32 (dense f32 MFMA peak 157.3 TFLOP/s)")}
     else:
         roof = roof_k7
     res = {
@@ -362,6 +390,13 @@ def main():
         "roofline_tile_backward": roof_k7,
         "kernels": kernels,
     }
+    res["deform_mode"] = {"mode": mode, "note": {
+        "exact_split": "default: fp32 operands split exactly into three bf16 pieces; the eight piece products above 2^-32 "
+                       "accumulate in fp32 on the bf16 MFMA (forward, kept data gradient, narrow-head weight gradients; wide head "
+                       "and dW1 on the f32 MFMA).  Results at the f32-MFMA kernels' error level (tests/test_deform_parity_gpu.py)",
+        "fp32_mfma": "every contraction on the f32-operand MFMA", "bf16x3": "REDUCED precision (two pieces, three products)"}[mode]}
+    if f32m is not None:
+        res["fp32_mfma_mode"] = f32m
     if b3 is not None:
         res["split_bf16_mode"] = b3
     if world == 1 and not a.no_cpu_baseline:

@@ -3230,15 +3230,18 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
 
 static bool use_b3(const ed3dgs_deform_cfg *c)
 {
-    return getenv("ED3DGS_DEFORM_BF16X3") && c->E == 32 && c->W <= 128 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+    return getenv("ED3DGS_DEFORM_BF16X3") && !getenv("ED3DGS_DEFORM_FP32_MFMA") && c->E == 32 && c->W <= 128 && !getenv("ED3DGS_DEFORM_NO_PIPE");
 }
-// bf16 pieces per value in the forward: 0 = exact-fp32 MFMA kernels, 2 = three products (ED3DGS_DEFORM_BF16X3),
-// 3 = six products, fp32-level accuracy (ED3DGS_DEFORM_BF16X6)
+// How the MLP multiplies.  3 (default): every fp32 operand is split EXACTLY into three bf16 pieces and the eight piece
+// products above 2^-32 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- each product more exact than one fp32
+// rounding, results at the fp32 kernels' error level against the reference's goldens (forward, kept data gradient,
+// narrow-head weight gradients; the rest stays on the f32 MFMA).  0: the v_mfma_f32_32x32x2_f32 kernels everywhere
+// (ED3DGS_DEFORM_FP32_MFMA=1).  2: two pieces, three products, ~1e-5 (ED3DGS_DEFORM_BF16X3=1, opt-in fast mode).
 static int fwd_pieces(const ed3dgs_deform_cfg *c)
 {
-    if (c->E != 32 || c->W > 128 || getenv("ED3DGS_DEFORM_NO_PIPE")) return 0;
-    if (getenv("ED3DGS_DEFORM_BF16X6")) return 3;
-    return getenv("ED3DGS_DEFORM_BF16X3") ? 2 : 0;
+    if (c->E != 32 || c->W > 128 || getenv("ED3DGS_DEFORM_NO_PIPE") || getenv("ED3DGS_DEFORM_FP32_MFMA")) return 0;
+    if (getenv("ED3DGS_DEFORM_BF16X3") && !getenv("ED3DGS_DEFORM_BF16X6")) return 2;
+    return 3;
 }
 
 static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
@@ -3539,6 +3542,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     }
     const int max_split = std::max(1, (cfg->P + 4 * WG_ROWS - 1) / (4 * WG_ROWS));
     const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
+    const bool pw5 = prof_start(ED3DGS_PROF_DEFORM_WGRAD_TRUNK, s);
     for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
         WgradArgs wa;
         std::memset(&wa, 0, sizeof wa);
@@ -3555,6 +3559,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         wa.blk_begin[wa.njobs] = nblk;
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3(nblk), dim3(256), wg_lds, s, wa);
     }
+    if (pw5) prof_stop(ED3DGS_PROF_DEFORM_WGRAD_TRUNK, s);
     // narrow heads and the wide head are separate launches (separate register allocations); each launch spreads its
     // jobs over ~2 blocks per CU
     for (int wide = 0; wide < 2; wide++) {
@@ -3572,6 +3577,8 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         ha.blk_begin[ha.njobs] = nblk;
         const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + (wide ? 48 * HJ_W : 0)) * sizeof(float);  // z, a, g_y slabs (+ W3)
         const bool b3 = use_b3(cfg);
+        const int sub = wide ? ED3DGS_PROF_DEFORM_WGRAD_WIDE : ED3DGS_PROF_DEFORM_WGRAD_NARROW;
+        const bool ps = prof_start(sub, s);
         if (wide) {
             const void *fn = b3 ? (const void *)deform_head_wgrad_kernel<true, true, false> : (const void *)deform_head_wgrad_kernel<true, false>;
             if (!check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
@@ -3593,6 +3600,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
             } else if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
             else hipLaunchKernelGGL((deform_head_wgrad_kernel<false, false>), dim3(nblk), dim3(256), lds, s, ha);
         }
+        if (ps) prof_stop(sub, s);
     }
     if (pw) prof_stop(ED3DGS_PROF_DEFORM_WGRAD, s);
     if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;

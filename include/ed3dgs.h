@@ -161,7 +161,10 @@ enum {
     ED3DGS_PROF_DEFORM_FORWARD = 2, /* deformation MLP forward kernel */
     ED3DGS_PROF_DEFORM_DGRAD = 3,   /* deformation MLP data-gradient kernel */
     ED3DGS_PROF_DEFORM_WGRAD = 4,   /* deformation MLP weight-gradient kernels (head + trunk launches together) */
-    ED3DGS_PROF_SLOTS = 5
+    ED3DGS_PROF_DEFORM_WGRAD_TRUNK = 5,  /* ... of which: deform_wgrad_kernel (dW1 / db1) */
+    ED3DGS_PROF_DEFORM_WGRAD_WIDE = 6,   /* ... the wide (SH) head's launch(es) */
+    ED3DGS_PROF_DEFORM_WGRAD_NARROW = 7, /* ... the narrow heads' launch */
+    ED3DGS_PROF_SLOTS = 8
 };
 int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask);  /* bit k = time slot k; every event pair costs
                                                                         * stream time, so time few kernels at once */

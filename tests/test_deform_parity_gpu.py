@@ -52,16 +52,19 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("b3", [False, True, 6], ids=["fp32", "split-bf16", "split-bf16x6-forward"])
+@pytest.mark.parametrize("mode", ["exact-split", "split-bf16x3", "fp32-mfma"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
-def test_golden_values_and_grads(path, b3, monkeypatch):
-    """Against the reference's own outputs; b3 = the opt-in split-bf16 MFMA kernels (ED3DGS_DEFORM_BF16X3=1), held to the
-    same 1e-4; 6 = the experimental three-piece / six-product forward (ED3DGS_DEFORM_BF16X6=1, fp32-level accuracy)."""
+def test_golden_values_and_grads(path, mode, monkeypatch):
+    """Against the reference's own outputs, tolerance 1e-4, in the three multiply modes of csrc/deform.hip: the default
+    (three exact bf16 pieces per fp32 operand, eight products), the f32-operand MFMA kernels (ED3DGS_DEFORM_FP32_MFMA=1)
+    and the opt-in reduced two-piece / three-product kernels (ED3DGS_DEFORM_BF16X3=1)."""
     _need_gpu()
-    if b3 == 6:
-        monkeypatch.setenv("ED3DGS_DEFORM_BF16X6", "1")
-    elif b3:
+    for v in ("ED3DGS_DEFORM_BF16X3", "ED3DGS_DEFORM_BF16X6", "ED3DGS_DEFORM_FP32_MFMA"):
+        monkeypatch.delenv(v, raising=False)
+    if mode == "split-bf16x3":
         monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
+    elif mode == "fp32-mfma":
+        monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
     z, a = _load(path)
     if int(z["cfg_D"]) > 1:
         net = _build(z, a)
@@ -112,8 +115,12 @@ def test_golden_values_and_grads(path, b3, monkeypatch):
     (66100, 128, False, dict(no_fine_deform=True)),
     # the opt-in split-bf16 MFMA kernels (forward, kept data gradient, narrow-head weight gradients)
     (5000, 128, True, dict(b3=True)), (65836, 128, True, dict(b3=True, no_dr=True)), (777, 64, True, dict(b3=True)),
+    # the f32-operand MFMA kernels
+    (5000, 128, True, dict(f32=True)), (5000, 128, False, dict(f32=True)), (65836, 128, True, dict(f32=True, no_dr=True)),
+    (777, 64, True, dict(f32=True)),
 ], ids=["5k", "5k-stateless", "w64", "tail", "tail-no_dr-no_dc", "tail-fine-only-no_ds", "tail-coarse-only-stateless",
-        "5k-split-bf16", "tail-split-bf16-no_dr", "w64-split-bf16"])
+        "5k-split-bf16", "tail-split-bf16-no_dr", "w64-split-bf16",
+        "5k-fp32-mfma", "5k-stateless-fp32-mfma", "tail-fp32-mfma-no_dr", "w64-fp32-mfma"])
 def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
     keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
@@ -126,6 +133,8 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     flags = dict(flags)
     if flags.pop("b3", False):
         monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
+    if flags.pop("f32", False):
+        monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
     a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
     torch.manual_seed(5)
     net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
