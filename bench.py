@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed extra passes in the MLP's other multiply modes (for profiles)")
     ap.add_argument("--dp-grads", action="store_true", help="also all-reduce the gradients every step (data-parallel training; not the headline configuration)")
     a = ap.parse_args()
 
@@ -268,7 +269,7 @@ def main():
 
     # ---- extras, not the headline: the same K steps / K renders with the deformation MLP in its other two modes ----
     def other_mode(var, note):
-        if not wl["deform"] or any(os.environ.get(v) for v in MODE_VARS):
+        if a.no_other_modes or not wl["deform"] or any(os.environ.get(v) for v in MODE_VARS):
             return None
         os.environ[var] = "1"      # read by the library at every call
         try:
@@ -316,7 +317,7 @@ def main():
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
-            if pj.get("workload") == a.workload and pj.get("mode", "fp32_mfma") == mode:
+            if pj.get("workload") == a.workload:
                 pmc = pj.get("hbm_bytes_per_launch", {})
         except Exception:
             pmc = {}
@@ -338,8 +339,8 @@ def main():
         2: ({"exact_split": "deform_forward_b3_kernel<4,3>", "bf16x3": "deform_forward_b3_kernel<4,2>", "fp32_mfma": "deform_forward_pipe_kernel<4>"}[mode], mac_all, npr),
         3: ({"exact_split": "deform_dgrad_kept_bn_kernel<4,3>", "bf16x3": "deform_dgrad_kept_b3_kernel<4>", "fp32_mfma": "deform_dgrad_kept_kernel<4>"}[mode], mac_all, npr),
         5: ("deform_wgrad_kernel (dW1)", mac_trunk, 1),
-        6: ({"exact_split": "deform_head_wgrad_kernel<true,false>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false>"}[mode], mac_wide, 3 if mode == "bf16x3" else 1),
-        7: ({"exact_split": "deform_head_wgrad_narrow_bn_kernel<3>", "bf16x3": "deform_head_wgrad_kernel<false,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false>"}[mode], mac_narrow, npr),
+        6: ({"exact_split": "deform_head_wgrad_kernel<true,false,true>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false,true>"}[mode], mac_wide, 3 if mode == "bf16x3" else 1),
+        7: ({"exact_split": "deform_head_wgrad_narrow_bn_kernel<3>", "bf16x3": "deform_head_wgrad_kernel<false,true,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false,true>"}[mode], mac_narrow, npr),
     }
     tfl = lambda mac, ms: 2.0 * mac * wl["P"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kernels = {
@@ -356,7 +357,7 @@ def main():
         kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-               "traffic": pmc.get("render_backward_kernel"),
+               "traffic": pmc.get("render_backward_kernel<false,true>"),
                "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1],
                "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
@@ -366,7 +367,7 @@ def main():
         eq = tfl(mac, avg_ms[dom])
         peak = MFMA_BF16_PEAK_TFLOPS if pr > 1 else MFMA_F32_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": nm, "achieved": eq * pr, "peak": peak, "unit": "TFLOP/s", "frac": eq * pr / peak,
-                "traffic": pmc.get(nm.split("<")[0].split(" ")[0]),
+                "traffic": pmc.get(nm.split(" ")[0]),
                 "algorithmic_flops_per_launch": 2.0 * mac * wl["P"], "executed_matrix_flops_per_launch": 2.0 * mac * wl["P"] * pr,
                 "fp32_equivalent_TFLOPs": eq, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
                 "note": ("dominant kernel of the step by time.  Algorithmic flops = 2 * %d MAC per Gaussian (fp32 multiplies); " % mac) +

@@ -1124,9 +1124,9 @@ __device__ __forceinline__ f32x16 gemm_tile_b3(const float *wl, const XSplit &x,
     return acc;
 }
 // N-piece forms (forward kernel): NP = 2 is the above; NP = 3 splits a value into three bf16 pieces that sum to it
-// EXACTLY (3 x 8 significant bits = the fp32 significand) and keeps the six products whose weight is above 2^-24 of the
-// leading one -- fp32-level accuracy (the dropped terms are of the size of one fp32 rounding) at 6 x 32 instead of
-// 16 x 64 MFMA cycles per 16-wide step.
+// EXACTLY (3 x 8 significant bits = the fp32 significand) and keeps the eight piece products whose weight is above
+// 2^-32 of the leading one (all but piece 2 x piece 2) -- each exact in fp32, so a multiply is more exact than one fp32
+// rounding -- at 8 x 32 instead of 8 x 64 MFMA cycles per 16-wide step.
 template <int NP>
 struct XSplitN {
     bf16x8 p[NP][2];

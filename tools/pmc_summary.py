@@ -30,18 +30,10 @@ for k, n, f, w, b in rows:
     if b < 1e5:
         continue
     lines.append("| %s | %d | %.0f | %.0f | %.1f |" % (k[:70].replace("|", "/"), n, f, w, b / 1e6))
-    m = re.search(r"ed3::(\w+)", k)
-    if m:
-        name = m.group(1)
-        if name == "render_backward_kernel" and "<false, true>" not in k:
-            continue
-        if name == "deform_head_wgrad_kernel":   # narrow + wide launches together make one weight-gradient pass
-            if re.search(r"<(true|false), false", k):      # exact-fp32 instantiations (the headline configuration)
-                out[name] = out.get(name, 0.0) + b
-            else:
-                out[name + "_split_bf16"] = out.get(name + "_split_bf16", 0.0) + b
-        elif name not in out:
-            out[name] = b
+    m = re.search(r"ed3::(\w+)(<[^>(]*>)?", k)
+    if m:   # keyed by kernel name incl. template arguments, e.g. "deform_forward_b3_kernel<4,3>"
+        name = m.group(1) + (m.group(2) or "").replace(" ", "")
+        out.setdefault(name, b)
 open(md, "w").write("\n".join(lines) + "\n")
 json.dump({"workload": "C3", "source": md + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
            "hbm_bytes_per_launch": out,
