@@ -149,6 +149,24 @@ size_t ed3dgs_filter3d_workspace_bytes(int P);
 int ed3dgs_compute_3d_filter(int P, const float *xyz, int n_cams, const float *cams, float *filter_3D,
                              char *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * simple_knn.distCUDA2 (submodules/simple-knn/simple_knn.cu:185-220, ext binding simple-knn/ext.cpp:15):
+ * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest OTHER points (exact k-NN; a slot with no
+ * neighbour counts FLT_MAX, as in the reference, so clouds of fewer than 4 points give huge / infinite values).
+ * points [P,3] and mean_dist2 [P] are device pointers; workspace >= ed3dgs_knn_workspace_bytes(P) device bytes.
+ * Fully asynchronous on `stream` (the reference synchronises twice for the cloud's bounding box).
+ */
+size_t ed3dgs_knn_workspace_bytes(int P);
+int ed3dgs_knn_mean_dist2(int P, const float *points, float *mean_dist2, char *workspace, size_t workspace_bytes,
+                          void *stream);
+/*
+ * The K nearest other points of every point, ascending: what utils/extra_utils.py:5-15 (o3d_knn) computes on the CPU for
+ * the embedding regulariser (train.py:218-223).  K must be 20.  sq_dists [P,K] float, indices [P,K] int64 (-1 where the
+ * cloud has fewer than K + 1 points; the distance there is FLT_MAX).  Ties are broken arbitrarily.
+ */
+int ed3dgs_knn_neighbours(int P, int K, const float *points, float *sq_dists, int64_t *indices, char *workspace,
+                          size_t workspace_bytes, void *stream);
+
 /* Measurement aid (bench.py): while enabled, the tile forward (K6) and tile backward (K7) launches are bracketed by
  * hipEvents on the stream they are launched on; ed3dgs_profile_end synchronises those events and returns the summed
  * kernel durations in milliseconds and the launch counts.  Not part of the data path. */
