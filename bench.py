@@ -60,7 +60,7 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     F = wl["frames"]
     inflight = []
     ups = [grads["color"], grads["depth"], grads["mdepth"], grads["normal"]]
-    ups_flat = torch.cat([g.reshape(-1) for g in ups])
+    ups_color_flat = grads["color"].reshape(-1)
     one = torch.ones((), device=device)
 
     def step(item, backward=True, coord=False):
@@ -71,11 +71,12 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
         if not backward:
             return pkg, None
         # fixed upstream gradients stand in for the L1/SSIM + depth-normal losses (the losses are outside the
-        # path): they enter the backward directly, and the scalar the ranks exchange is <outputs, upstream gradients>
+        # path): they enter the backward directly
         outs = [pkg["render"], pkg["expected_depth"], pkg["median_depth"], pkg["normal"]]
         torch.autograd.backward(outs, ups)
         with torch.no_grad():
-            loss = torch.vdot(torch.cat([o.reshape(-1) for o in outs]), ups_flat)
+            # logging stand-in (train.py logs the image loss and PSNR): <image, its upstream gradient> and a PSNR
+            loss = torch.vdot(pkg["render"].reshape(-1), ups_color_flat)
             mse = (pkg["render"] - 0.5).square().mean()
             stats = torch.stack([loss, -10.0 * torch.log10(mse), one])
         # the path's one collective (RCCL over xGMI): 12 bytes, waited for one step later (the stream, not the host,
