@@ -166,10 +166,48 @@ class SynthGaussianModel:
         self.filter_3D = torch.zeros([self.get_xyz.shape[0], 1], device=self.get_xyz.device)
 
 
-def load_checkpoint(model_path, iteration, args=None, sh_degree=3, device="cuda"):
+def read_cfg_args(model_path):
+    """`<model_path>/cfg_args` (train.py:483-484 writes `str(Namespace(**vars(args)))`; arguments/__init__.py:174-194 reads
+    it back with eval()).  Parsed here with `ast` -- literals only, nothing in the file is executed.  Returns a
+    SimpleNamespace; a missing file gives an empty one (as the reference's `Namespace()` default)."""
+    import ast
+    path = os.path.join(model_path, "cfg_args")
+    if not os.path.exists(path):
+        return SimpleNamespace()
+    tree = ast.parse(open(path).read().strip(), mode="eval")
+    call = tree.body
+    if not (isinstance(call, ast.Call) and isinstance(call.func, ast.Name) and call.func.id == "Namespace" and not call.args):
+        raise ValueError("cfg_args: expected `Namespace(key=value, ...)`")
+    out = {}
+    for kw in call.keywords:
+        if kw.arg is None:
+            raise ValueError("cfg_args: **kwargs are not allowed")
+        try:
+            out[kw.arg] = ast.literal_eval(kw.value)
+        except ValueError:
+            raise ValueError("cfg_args: value of %r is not a literal" % kw.arg)
+    return SimpleNamespace(**out)
+
+
+def write_cfg_args(model_path, args):
+    """train.py:483-484: the run's arguments as `Namespace(...)` text."""
+    from argparse import Namespace
+    os.makedirs(model_path, exist_ok=True)
+    with open(os.path.join(model_path, "cfg_args"), "w") as f:
+        f.write(str(Namespace(**vars(args))))
+
+
+def load_checkpoint(model_path, iteration, args=None, sh_degree=None, device="cuda"):
     """A render-ready model from `<model_path>/point_cloud/iteration_<n>/{point_cloud.ply, deformation.pth}` (the layout
-    scene/__init__.py writes: Scene.save -> save_ply + save_deformation)."""
+    scene/__init__.py writes: Scene.save -> save_ply + save_deformation).  Hyper-parameters not given in `args` and the
+    SH degree come from `<model_path>/cfg_args` when that file exists (read_cfg_args), else the defaults."""
     from .synthetic import make_scene
+    cfg = read_cfg_args(model_path)
+    if args is None:
+        known = vars(default_hyper())
+        args = default_hyper(**{k: v for k, v in vars(cfg).items() if k in known})
+    if sh_degree is None:
+        sh_degree = int(getattr(cfg, "sh_degree", 3))
     d = os.path.join(model_path, "point_cloud", "iteration_%d" % iteration)
     m = SynthGaussianModel(make_scene(1, sh_degree=sh_degree), args=args, device=device, table_scale=1.0)
     m.load_ply(os.path.join(d, "point_cloud.ply"), device=device)

@@ -6,6 +6,7 @@ import sys
 from types import SimpleNamespace
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -110,3 +111,19 @@ def test_compute_3d_filter_known_answers():
     assert F.compute_3D_filter(xyz[1:3], [_cam()]).max() == 0.0   # nothing seen at all
     rows = F.camera_rows([_cam(W=200, H=100)])
     assert rows.shape == (1, 16) and abs(rows[0, 12] - 100.0) < 1e-4 and abs(rows[0, 13] - 50.0) < 1e-4
+
+
+def test_cfg_args_is_parsed_without_eval(tmp_path):
+    """arguments/__init__.py:174-194 evals the file; here only literals are accepted."""
+    from argparse import Namespace
+    from ed3dgs_amd.model import read_cfg_args, write_cfg_args
+    ns = Namespace(sh_degree=3, net_width=64, source_path="/data/x y", white_background=False, lr=1.6e-4, cams=[1, 2], none=None)
+    write_cfg_args(str(tmp_path), ns)
+    assert open(tmp_path / "cfg_args").read() == str(ns)          # train.py:483-484
+    got = read_cfg_args(str(tmp_path))
+    assert vars(got) == vars(ns)
+    assert vars(read_cfg_args(str(tmp_path / "missing"))) == {}
+    for bad in ("Namespace(a=__import__('os').system('true'))", "print(1)", "Namespace(1)", "Namespace(**{})"):
+        (tmp_path / "cfg_args").write_text(bad)
+        with pytest.raises(ValueError):
+            read_cfg_args(str(tmp_path))
