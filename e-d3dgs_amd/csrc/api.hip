@@ -107,6 +107,75 @@ struct StageCheck {
 
 using namespace ed3;
 
+namespace {
+// Preprocess + binning (K1-K5), shared by the rasterizer forward and the point integration: fills the geometry / image /
+// binning states and returns the instance count (or a negative error code).
+int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_alloc_fn binning_alloc, void *binning_user,
+                  ed3dgs_alloc_fn image_alloc, void *image_user, int P, int D, int M, int width, int height,
+                  const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+                  const float *tongue_class, const float *scales, float scale_modifier, const float *rotations,
+                  const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                  float tan_fovx, float tan_fovy, float kernel_size, int *radii, float *invraycov, uint8_t *condition,
+                  StageCheck &ok, hipStream_t s, GeometryState &geom, ImageState &img, BinningState &bin)
+{
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    char *chunk = geometry_alloc(geometry_user, ed3dgs_geometry_bytes(P));
+    if (!chunk) { set_error("geometry allocation failed"); return ED3DGS_ERR_ALLOC; }
+    geom = GeometryState::from_chunk(chunk, P);
+    char *img_chunk = image_alloc(image_user, ed3dgs_image_bytes(width, height));
+    if (!img_chunk) { set_error("image allocation failed"); return ED3DGS_ERR_ALLOC; }
+    const size_t T = tiles_of(width, height);
+    img = ImageState::from_chunk(img_chunk, (size_t)width * height, T);
+
+    launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
+                      colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
+                      focal_y, kernel_size, radii, geom, s, invraycov, condition);
+    if (!ok("preprocess")) return ED3DGS_ERR_HIP;
+    if (!run_scan(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.point_offsets, P, s)) return ED3DGS_ERR_HIP;
+    if (!ok("scan")) return ED3DGS_ERR_HIP;
+    // The one read-back of the path (CR/rasterizer_impl.cu:359: the instance count sizes the binning buffers).  The copy
+    // goes to pinned memory and is followed by an event; the work that does not need the count -- binning level 1
+    // (binning.hip: Gaussians by depth, then the instance offsets in that order) and clearing the tile ranges -- is
+    // enqueued BEHIND the copy, and the host waits for the event only.  By the time the GPU has finished the level-1
+    // sort the host has allocated the binning buffers and enqueued the rest, so the stream never runs dry (the
+    // reference's cudaMemcpy drains it).
+    static thread_local struct Readback {
+        uint32_t *host = nullptr;
+        hipEvent_t ev = nullptr;
+    } rb;
+    if (!rb.host) {
+        if (!check_hip(hipHostMalloc((void **)&rb.host, 64, hipHostMallocDefault), "pinned read-back buffer") ||
+            !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
+    }
+    if (!check_hip(hipMemcpyAsync(rb.host, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
+    if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
+    if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
+    if (!ok("depth order")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
+    const uint32_t num_rendered_u = *rb.host;
+    if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
+    const int R = (int)num_rendered_u;
+
+    char *bin_chunk = binning_alloc(binning_user, ed3dgs_binning_bytes(R));
+    if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
+    bin = BinningState::from_chunk(bin_chunk, R);
+
+    launch_duplicate_with_keys(P, geom, radii, width, height, bin.tile_keys_unsorted, bin.point_list_unsorted, s);
+    if (!ok("duplicateWithKeys")) return ED3DGS_ERR_HIP;
+    const int bit = (int)higher_msb((uint32_t)T);
+    if (!run_sort(bin.sort_space, bin.sort_size, bin.tile_keys_unsorted, bin.tile_keys, bin.point_list_unsorted, bin.point_list, R, bit, s)) return ED3DGS_ERR_HIP;
+    if (!ok("sort")) return ED3DGS_ERR_HIP;
+    launch_identify_tile_ranges(R, bin.tile_keys, img.ranges, s);
+    if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
+
+    return R;
+}
+}  // namespace
+
 extern "C" {
 
 const char *ed3dgs_last_error(void) { return g_error.c_str(); }
@@ -167,57 +236,14 @@ int ed3dgs_rasterize_forward(
 
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
-
-    char *chunk = geometry_alloc(geometry_user, ed3dgs_geometry_bytes(P));
-    if (!chunk) { set_error("geometry allocation failed"); return ED3DGS_ERR_ALLOC; }
-    GeometryState geom = GeometryState::from_chunk(chunk, P);
-    char *img_chunk = image_alloc(image_user, ed3dgs_image_bytes(width, height));
-    if (!img_chunk) { set_error("image allocation failed"); return ED3DGS_ERR_ALLOC; }
-    const size_t T = tiles_of(width, height);
-    ImageState img = ImageState::from_chunk(img_chunk, (size_t)width * height, T);
-
-    launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
-                      colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
-                      focal_y, kernel_size, radii, geom, s);
-    if (!ok("preprocess")) return ED3DGS_ERR_HIP;
-    if (!run_scan(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.point_offsets, P, s)) return ED3DGS_ERR_HIP;
-    if (!ok("scan")) return ED3DGS_ERR_HIP;
-    // The one read-back of the path (CR/rasterizer_impl.cu:359: the instance count sizes the binning buffers).  The copy
-    // goes to pinned memory and is followed by an event; the work that does not need the count -- binning level 1
-    // (binning.hip: Gaussians by depth, then the instance offsets in that order) and clearing the tile ranges -- is
-    // enqueued BEHIND the copy, and the host waits for the event only.  By the time the GPU has finished the level-1
-    // sort the host has allocated the binning buffers and enqueued the rest, so the stream never runs dry (the
-    // reference's cudaMemcpy drains it).
-    static thread_local struct Readback {
-        uint32_t *host = nullptr;
-        hipEvent_t ev = nullptr;
-    } rb;
-    if (!rb.host) {
-        if (!check_hip(hipHostMalloc((void **)&rb.host, 64, hipHostMallocDefault), "pinned read-back buffer") ||
-            !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
-    }
-    if (!check_hip(hipMemcpyAsync(rb.host, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
-    if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
-    if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
-    if (!ok("depth order")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
-    const uint32_t num_rendered_u = *rb.host;
-    if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
-    const int R = (int)num_rendered_u;
-
-    char *bin_chunk = binning_alloc(binning_user, ed3dgs_binning_bytes(R));
-    if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
-    BinningState bin = BinningState::from_chunk(bin_chunk, R);
-
-    launch_duplicate_with_keys(P, geom, radii, width, height, bin.tile_keys_unsorted, bin.point_list_unsorted, s);
-    if (!ok("duplicateWithKeys")) return ED3DGS_ERR_HIP;
-    const int bit = (int)higher_msb((uint32_t)T);
-    if (!run_sort(bin.sort_space, bin.sort_size, bin.tile_keys_unsorted, bin.tile_keys, bin.point_list_unsorted, bin.point_list, R, bit, s)) return ED3DGS_ERR_HIP;
-    if (!ok("sort")) return ED3DGS_ERR_HIP;
-    launch_identify_tile_ranges(R, bin.tile_keys, img.ranges, s);
-    if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
+    GeometryState geom;
+    ImageState img;
+    BinningState bin;
+    const int R = bin_gaussians(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
+                                width, height, means3D, shs, colors_precomp, opacities, tongue_class, scales, scale_modifier,
+                                rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size,
+                                radii, nullptr, nullptr, ok, s, geom, img, bin);
+    if (R < 0) return R;
 
     const bool pf = prof_start(ED3DGS_PROF_TILE_FORWARD, s);
     launch_render_forward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
@@ -284,6 +310,54 @@ int ed3dgs_rasterize_backward(
                                dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s);
     if (!ok("preprocess backward")) return ED3DGS_ERR_HIP;
     return 0;
+}
+
+size_t ed3dgs_integrate_point_bytes(int PN, int width, int height) { return integrate_point_bytes(PN, width, height); }
+size_t ed3dgs_integrate_workspace_bytes(int R, int width, int height) { return integrate_workspace_bytes(R, width, height); }
+
+int ed3dgs_integrate(
+    ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_alloc_fn binning_alloc, void *binning_user,
+    ed3dgs_alloc_fn image_alloc, void *image_user, ed3dgs_alloc_fn point_alloc, void *point_user,
+    ed3dgs_alloc_fn point_binning_alloc, void *point_binning_user, int PN, int P, int D, int M, const float *background,
+    int width, int height, const float *points3D, const float *means3D, const float *shs, const float *colors_precomp,
+    const float *opacities, const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx, float tan_fovy,
+    float kernel_size, int prefiltered, float *out_color, float *accum_alpha, float *invraycov, int *radii,
+    float *out_alpha_integrated, float *out_color_integrated, float *out_coordinate2d, float *out_sdf,
+    unsigned char *condition, int debug, void *stream)
+{
+    (void)prefiltered;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || PN < 0 || width <= 0 || height <= 0) { set_error("ed3dgs_integrate: bad P/PN/width/height"); return ED3DGS_ERR_INVALID; }
+    if (!geometry_alloc || !binning_alloc || !image_alloc || !point_alloc || !point_binning_alloc) { set_error("ed3dgs_integrate: null allocator"); return ED3DGS_ERR_INVALID; }
+    if (P == 0 || PN == 0) return 0;  // DGR/rasterize_points.cu:345
+    if (!points3D || !means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background || !radii || !out_color ||
+        !accum_alpha || !invraycov || !out_alpha_integrated || !out_color_integrated || !out_coordinate2d || !out_sdf || !condition) {
+        set_error("ed3dgs_integrate: null required pointer"); return ED3DGS_ERR_INVALID;
+    }
+    if (!colors_precomp && !shs) { set_error("For non-RGB, provide precomputed Gaussian colors!"); return ED3DGS_ERR_INVALID; }   // CR/rasterizer_impl.cu:643-646
+    if (!cov3D_precomp && (!scales || !rotations)) { set_error("ed3dgs_integrate: need scales+rotations or cov3D_precomp"); return ED3DGS_ERR_INVALID; }
+    if (shs && !colors_precomp && (M < (D + 1) * (D + 1) || D < 0 || D > 3)) { set_error("ed3dgs_integrate: SH degree/coeff mismatch"); return ED3DGS_ERR_INVALID; }
+    StageCheck ok{debug != 0, s};
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    GeometryState geom;
+    ImageState img;
+    BinningState bin;
+    const int R = bin_gaussians(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
+                                width, height, means3D, shs, colors_precomp, opacities, nullptr, scales, scale_modifier,
+                                rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size,
+                                radii, invraycov, condition, ok, s, geom, img, bin);
+    if (R < 0) return R;
+    char *pchunk = point_alloc(point_user, ed3dgs_integrate_point_bytes(PN, width, height));
+    char *wchunk = point_binning_alloc(point_binning_user, ed3dgs_integrate_workspace_bytes(R, width, height));
+    if (!pchunk || !wchunk) { set_error("integrate: point-state allocation failed"); return ED3DGS_ERR_ALLOC; }
+    const int point_bits = (int)higher_msb((uint32_t)tiles_of(width, height) + 1);
+    if (!launch_integrate(PN, R, width, height, points3D, viewmatrix, focal_x, focal_y, img.ranges, bin.point_list, geom.rec,
+                          invraycov, condition, background, pchunk, wchunk, out_color, accum_alpha, out_alpha_integrated,
+                          out_color_integrated, out_coordinate2d, out_sdf, point_bits, s)) return ED3DGS_ERR_HIP;
+    if (!ok("integrate")) return ED3DGS_ERR_HIP;
+    return R;
 }
 
 int ed3dgs_profile_begin(int max_samples)

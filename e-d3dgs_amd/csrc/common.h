@@ -77,7 +77,8 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                        const float *rotations, const float *opacities, const float *tongue, const float *shs,
                        const float *cov3D_precomp, const float *colors_precomp, const float *view, const float *proj,
                        const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-                       float kernel_size, int *radii, GeometryState g, hipStream_t s);
+                       float kernel_size, int *radii, GeometryState g, hipStream_t s, float *invraycov = nullptr,
+                       uint8_t *condition = nullptr);
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s);
 void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint32_t *tile_keys,
                                 uint32_t *values, hipStream_t s);
@@ -105,6 +106,14 @@ void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t
                             const float *dL_dpix, const float *dL_dcoord, const float *dL_dmcoord,
                             const float *dL_ddepth, const float *dL_dmdepth, const float *dL_dalpha,
                             const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s);
+// integrate.hip (point integration: K12-K14)
+size_t integrate_point_bytes(int PN, int width, int height);
+size_t integrate_workspace_bytes(int R, int width, int height);
+bool launch_integrate(int PN, int R, int W, int H, const float *points3D, const float *view, float focal_x, float focal_y,
+                      const uint32_t *ranges, const uint32_t *point_list, const float *rec, const float *invraycov,
+                      const uint8_t *condition, const float *bg, char *point_chunk, char *work_chunk, float *out_color,
+                      float *accum_alpha, float *out_alpha_integrated, float *out_color_integrated,
+                      float *out_coordinate2d, float *out_sdf, int point_end_bit, hipStream_t s);
 void launch_preprocess_backward(int P, int D, int M, const float *means, const int *radii, const float *shs,
                                 const float *scales, const float *rotations, float scale_modifier,
                                 const float *cov3D_precomp, const float *view, const float *proj, const float *campos,

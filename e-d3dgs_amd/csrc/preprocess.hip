@@ -73,8 +73,12 @@ __device__ inline void cov3d_from_scale_rot(v3 scale, float mod, float4 rot, flo
 
 struct Cov2DOut { float cov[3]; float cam_plane[6]; float normal[3]; float ray_plane[2]; float coef; };
 
-__device__ inline void cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
-                                    float kernel_size, const float *cov3D, const float *__restrict__ view, Cov2DOut &o)
+// INTE: also the inverse covariance in ray space (6 unique entries) that the point integration evaluates
+// (CR/forward.cu:187-235); returns `well_conditioned` (the per-Gaussian `condition` flag of the integrate path).
+template <bool INTE = false>
+__device__ inline bool cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                                    float kernel_size, const float *cov3D, const float *__restrict__ view, Cov2DOut &o,
+                                    float *inv6 = nullptr)
 {
     v3 t = xform4x3(mean, view);
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
@@ -127,6 +131,40 @@ __device__ inline void cov2d_planes(v3 mean, float focal_x, float focal_y, float
         float l = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
         m3 nJ = cols3(1 / t.z, 0.0f, -(t.x) / (t.z * t.z), 0.0f, 1 / t.z, -(t.y) / (t.z * t.z), t.x / l, t.y / l, t.z / l);
         m3 nJ_inv = cols3(v2 + 1, -uv, 0, -uv, u2 + 1, 0, -txtz, -tytz, 0);
+        if constexpr (INTE) {
+            m3 inv_cov_ray;
+            if (well_conditioned) {
+                const float ltz = u2 + v2 + 1;
+                const m3 full = scale3(cols3(v2 + 1, -uv, txtz / l * ltz, -uv, u2 + 1, tytz / l * ltz, -txtz, -tytz, 1 / l * ltz),
+                                       t.z / (u2 + v2 + 1));
+                const m3 T2 = mul3(Wm, tr3(full));
+                inv_cov_ray = mul3(mul3(tr3(T2), Vrk_inv), T2);
+            } else {
+                // The reference assigns this branch's result to a block-local that shadows the matrix it then uses
+                // (CR/forward.cu:219), i.e. it reads an uninitialised matrix; what the branch computes is used here.
+                const m3 T2 = mul3(Wm, nJ);
+                const m3 cov_ray = mul3(mul3(tr3(T2), Vrk_inv), T2);
+                m3 cvec; float cval[3];
+                eig_sym3(cov_ray, cval, cvec);
+                const unsigned mid = cval[0] > cval[1] ? (cval[1] > cval[2] ? 2 : 1) : (cval[0] > cval[2] ? 2 : 0);
+                const float lambda1 = cval[(mid + 1) % 3], lambda2 = cval[(mid + 2) % 3];
+                m3 nv;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    nv.m[0][q] = cvec.m[(mid + 1) % 3][q];
+                    nv.m[1][q] = cvec.m[(mid + 2) % 3][q];
+                    nv.m[2][q] = cvec.m[mid][q];
+                }
+                const v3 r3 = mk3(nv.m[0][2], nv.m[1][2], nv.m[2][2]);
+                const m3 c2d = cols3(1 / lambda1, 0, -r3.x / r3.z / lambda1, 0, 1 / lambda2, -r3.y / r3.z / lambda2,
+                                     -r3.x / r3.z / lambda1, -r3.y / r3.z / lambda2, 0);
+                inv_cov_ray = mul3(mul3(nv, c2d), tr3(nv));
+            }
+            const m3 sc = cols3(1 / focal_x, 0, 0, 0, 1 / focal_y, 0, 0, 0, 1);
+            inv_cov_ray = mul3(mul3(sc, inv_cov_ray), sc);
+            inv6[0] = inv_cov_ray.m[0][0]; inv6[1] = inv_cov_ray.m[0][1]; inv6[2] = inv_cov_ray.m[0][2];
+            inv6[3] = inv_cov_ray.m[1][1]; inv6[4] = inv_cov_ray.m[1][2]; inv6[5] = inv_cov_ray.m[2][2];
+        }
         float vbn = dot3(uvh_mn, uvh);
         float factor_normal = l / (u2 + v2 + 1);
         v3 plane = mulv3(nJ_inv, uvh_mn / fmaxf(vbn, 0.0000001f));
@@ -144,8 +182,10 @@ __device__ inline void cov2d_planes(v3 mean, float focal_x, float focal_y, float
         v3 n = normalize3(cam_normal);
         o.normal[0] = n.x; o.normal[1] = n.y; o.normal[2] = n.z;
     }
+    return well_conditioned;
 }
 
+template <bool INTE>
 __global__ void __launch_bounds__(256) preprocess_kernel(
     int P, int D, int M, const float *__restrict__ means, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ tongue,
@@ -154,7 +194,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size, int *__restrict__ radii,
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
-    uint32_t *__restrict__ ids, int gx, int gy)
+    uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
@@ -180,7 +220,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
 #pragma unroll
         for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = cov3D[i];
         Cov2DOut c2;
-        cov2d_planes(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, c2);
+        if constexpr (INTE) {
+            float inv6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool wc = cov2d_planes<true>(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, c2, inv6);
+            condition[idx] = wc ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) invraycov[6 * (size_t)idx + i] = inv6[i];   // zeros where the reference leaves its zero fill
+        } else {
+            cov2d_planes<false>(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, c2);
+        }
         float ts = sqrtf(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
         float cx = c2.cov[0], cy = c2.cov[1], cz = c2.cov[2];
         float det = (cx * cz - cy * cy);
@@ -208,7 +256,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         float4 *r4 = reinterpret_cast<float4 *>(rec + (size_t)idx * REC);
         r4[0] = make_float4(pix_x, pix_y, conx, cony);
         r4[1] = make_float4(conz, opacities[idx] * c2.coef, rgb.x, rgb.y);
-        r4[2] = make_float4(rgb.z, tongue[idx], ts, c2.ray_plane[0]);
+        r4[2] = make_float4(rgb.z, tongue ? tongue[idx] : 0.f, ts, c2.ray_plane[0]);
         r4[3] = make_float4(c2.ray_plane[1], c2.normal[0], c2.normal[1], c2.normal[2]);
         float4 *c4 = reinterpret_cast<float4 *>(rec_coord + (size_t)idx * RECC);
         c4[0] = make_float4(c2.cam_plane[0], c2.cam_plane[1], c2.cam_plane[2], c2.cam_plane[3]);
@@ -288,13 +336,20 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                        const float *rotations, const float *opacities, const float *tongue, const float *shs,
                        const float *cov3D_precomp, const float *colors_precomp, const float *view, const float *proj,
                        const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-                       float kernel_size, int *radii, GeometryState g, hipStream_t s)
+                       float kernel_size, int *radii, GeometryState g, hipStream_t s, float *invraycov, uint8_t *condition)
 {
     int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
-                       scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
-                       campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
-                       g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy);
+    if (invraycov)   // the integrate path's variant (CR/forward.cu:875-945 with integrate = true)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
+                           scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
+                           campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
+                           g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
+                           scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
+                           campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
+                           g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, (float *)nullptr,
+                           (uint8_t *)nullptr);
 }
 
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s)

@@ -165,9 +165,58 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present
 
 
-def integrate_gaussians_to_points(*args, **kwargs):
-    # DGR/rasterize_points.cu:273-392 (mesh-extraction probe).  SURVEY section 8(f) rank 1: next, not built yet.
-    raise NotImplementedError("integrate_gaussians_to_points is outside this round's hot-path scope (SURVEY 8f.1)")
+def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                  cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                  kernel_size, subpixel_offset, image_height, image_width, sh, degree, campos,
+                                  prefiltered, debug):
+    """IntegrateGaussiansToPointsCUDA (DGR/rasterize_points.cu:273-392): same 23 positional arguments, same 10-tuple
+    (num_rendered, out_color [9,H,W], alpha_integrated [PN], color_integrated [PN,3], coordinate2d [PN,2], sdf [PN],
+    radii [P], geomBuffer, binningBuffer, imgBuffer).  `view2gaussian_precomp` and `subpixel_offset` are accepted and
+    ignored, as the reference's kernels ignore their values."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if points3D.dim() != 2 or points3D.size(1) != 3:
+        raise RuntimeError("points3D must have dimensions (num_points, 3)")
+    L = _lib.lib()
+    PN, P = points3D.size(0), means3D.size(0)
+    H, W = _num(image_height, int), _num(image_width, int)
+    dev = means3D.device
+    means3D = _f32c(means3D, "means3D"); points3D = _f32c(points3D, "points3D")
+    colors = _f32c(colors, "colors_precomp"); opacity = _f32c(opacity, "opacities"); scales = _f32c(scales, "scales")
+    rotations = _f32c(rotations, "rotations"); cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp")
+    sh = _f32c(sh, "sh"); background = _f32c(background, "bg")
+    viewmatrix = _f32c(viewmatrix, "viewmatrix"); projmatrix = _f32c(projmatrix, "projmatrix")
+    campos = _f32c(campos, "campos")
+    fopt = dict(dtype=torch.float32, device=dev)
+    out_color = torch.zeros((9, H, W), **fopt)
+    accum_alpha = torch.zeros((1, H, W), **fopt)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    out_alpha_integrated = torch.ones((PN,), **fopt)
+    out_color_integrated = torch.zeros((PN, 3), **fopt)
+    out_coordinate2d = torch.zeros((PN, 2), **fopt)
+    out_sdf = torch.full((PN,), -1000.0, **fopt)
+    invraycov = torch.zeros((P, 6), **fopt)
+    condition = torch.zeros((P,), dtype=torch.uint8, device=dev)
+    geom, binning, img, pts, ptsbin = _Grow(dev), _Grow(dev), _Grow(dev), _Grow(dev), _Grow(dev)
+    rendered = 0
+    if P != 0 and PN != 0:
+        M = sh.size(1) if sh.numel() else 0
+        rendered = L.ed3dgs_integrate(
+            geom.cb, None, binning.cb, None, img.cb, None, pts.cb, None, ptsbin.cb, None, C.c_int(PN), C.c_int(P),
+            C.c_int(_num(degree, int)), C.c_int(M), _ptr(background), C.c_int(W), C.c_int(H), _ptr(points3D), _ptr(means3D),
+            _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), C.c_float(_num(scale_modifier, float)), _ptr(rotations),
+            _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), C.c_float(_num(tan_fovx, float)),
+            C.c_float(_num(tan_fovy, float)), C.c_float(_num(kernel_size, float)), C.c_int(bool(prefiltered)),
+            _ptr(out_color), _ptr(accum_alpha), _ptr(invraycov), _ptr(radii), _ptr(out_alpha_integrated),
+            _ptr(out_color_integrated), _ptr(out_coordinate2d), _ptr(out_sdf), _ptr(condition), C.c_int(bool(debug)),
+            _stream())
+        if rendered < 0:
+            raise RuntimeError(_lib.last_error())
+    if KEEP_LAST:
+        LAST.update(P=P, H=H, W=W, R=rendered, geom=geom.t, binning=binning.t, img=img.t, invraycov=invraycov,
+                    condition=condition, accum_alpha=accum_alpha)
+    return (rendered, out_color, out_alpha_integrated, out_color_integrated, out_coordinate2d, out_sdf, radii, geom.t,
+            binning.t, img.t)
 
 
 def n_contrib_view(P, H, W, R, geomBuffer, imageBuffer):

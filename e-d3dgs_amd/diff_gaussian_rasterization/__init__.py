@@ -152,6 +152,28 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, tongue_class, scales, rotations,
                                    cov3D_precomp, self.raster_settings)
 
-    def integrate(self, *args, **kwargs):
-        # GaussianRasterizer.integrate (:245-312) is the mesh-extraction probe: SURVEY 8(f) rank 1, not in this round.
-        return _C.integrate_gaussians_to_points(*args, **kwargs)
+    def integrate(self, points3D, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                  cov3D_precomp=None, view2gaussian_precomp=None):
+        """GaussianRasterizer.integrate (DGR/diff_gaussian_rasterization/__init__.py:245-312): the mesh-extraction probe.
+        Returns (color [9,H,W], alpha_integrated, color_integrated, point_coordinate, point_sdf, radii)."""
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        view2gaussian_precomp = empty if view2gaussian_precomp is None else view2gaussian_precomp
+        # the reference passes kernel_size 0.0 and an all-zero subpixel_offset here (:271, :289); the offset is unused
+        args = (rs.bg, points3D, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3D_precomp,
+                view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, 0.0, None, rs.image_height,
+                rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        with torch.no_grad():
+            (num_rendered, color, alpha_integrated, color_integrated, point_coordinate, point_sdf, radii, geomBuffer,
+             binningBuffer, imgBuffer) = _C.integrate_gaussians_to_points(*args)
+        return color, alpha_integrated, color_integrated, point_coordinate, point_sdf, radii

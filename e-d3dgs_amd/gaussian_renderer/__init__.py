@@ -6,7 +6,7 @@ keys (:128-142), so train.py / render.py call them unchanged.  What differs is h
     that pybind turns back into host scalars -> six device syncs per call, :29-37);
   * the camera time is passed to the deformation network as a float (no (P,1) tensor, :45);
   * deformation = one fused HIP launch per direction, activations fused, rasterizer = HIP tile kernels.
-`render_old` / `integrate` (DGR-old and mesh probing) are outside this round's hot-path scope.
+`integrate` (mesh probing) is below; `render_old` (DGR-old) is outside the scope.
 """
 import math
 
@@ -154,3 +154,48 @@ def render_without_tongue(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, ke
     return _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord,
                         require_depth, override_color, cam_no, iter, num_down_emb_c, num_down_emb_f, disable_filter3D,
                         -1)
+
+
+def integrate(points3D, viewpoint_camera, pc, pipe, bg_color: torch.Tensor, kernel_size: float, loaded_iter,
+              scaling_modifier=1.0, override_color=None, num_down_emb_c=5, num_down_emb_f=5):
+    """gaussian_renderer.integrate (gaussian_renderer/__init__.py:551-661): deform the Gaussians at the camera's time
+    (cam_no = None), apply the 3D-filter activations, and integrate them at `points3D` (mesh_extract_tetrahedra.py:90-124).
+    Inference only: nothing here is differentiated (the reference's rasterizer.integrate has no backward either)."""
+    with torch.no_grad():
+        raster_settings = _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, True, True)
+        rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+        means3D = pc.get_xyz
+        screenspace_points = torch.zeros_like(means3D)
+        (means3D_final, scales_deformed, rotations_deformed, opacity_deformed, shs_final, extras) = pc._deformation(
+            means3D, pc._scaling, pc._rotation, pc._opacity, float(viewpoint_camera.time), None, pc, None, pc.get_features,
+            iter=loaded_iter, num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f)
+        scales_final = rotations_final = cov3D_precomp = None
+        if pipe.compute_cov3D_python:
+            # the reference leaves opacity_final undefined on this branch (:606-607 vs :649); the filtered opacity is used
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+            _, opacity_final = pc.apply_scaling_n_opacity_with_3D_filter(opacity=opacity_deformed, scales=scales_deformed)
+        else:
+            scales_final, opacity_final = pc.apply_scaling_n_opacity_with_3D_filter(opacity=opacity_deformed,
+                                                                                    scales=scales_deformed)
+            rotations_final = pc.rotation_activation(rotations_deformed)
+        colors_precomp = None
+        shs = shs_final
+        if override_color is not None:
+            colors_precomp, shs = override_color, None
+        elif pipe.convert_SHs_python:
+            from utils.sh_utils import eval_sh
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.to(means3D.device).repeat(pc.get_features.shape[0], 1)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+            shs = None   # the reference passes both here and its rasterizer raises (:651-652)
+        rendered_image, alpha_integrated, color_integrated, point_coordinate, point_sdf, radii = rasterizer.integrate(
+            points3D=points3D, means3D=means3D_final, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+            opacities=opacity_final, scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp,
+            view2gaussian_precomp=None)
+    return {"render": rendered_image,
+            "alpha_integrated": alpha_integrated,
+            "color_integrated": color_integrated,
+            "point_coordinate": point_coordinate,
+            "point_sdf": point_sdf,
+            "visibility_filter": radii > 0,
+            "radii": radii}

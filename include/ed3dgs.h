@@ -150,6 +150,32 @@ int ed3dgs_compute_3d_filter(int P, const float *xyz, int n_cams, const float *c
                              char *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * CudaRasterizer::Rasterizer::integrate (CR/rasterizer.h:113-150, CR/rasterizer_impl.cu:580-851; torch binding
+ * IntegrateGaussiansToPointsCUDA, DGR/rasterize_points.cu:273-392): renders the Gaussians with the 5-sample
+ * transmittance of the mesh-extraction path and integrates alpha at PN query points.  Returns num_rendered (>= 0) or an
+ * error code.  Differences to the reference signature: `subpixel_offset` and `depths_plane_precomp` are dropped (the
+ * reference never uses their values); `condition` has P entries (the reference allocates PN and indexes by Gaussian).
+ * Caller-filled, as IntegrateGaussiansToPointsCUDA does: out_color [9,H,W] zeros (channels 0-2 colour, 3 expected ray
+ * distance, 4 median, 6 maximal, 7 alpha, 8 number of query points of the pixel), accum_alpha [H,W] zeros (final T),
+ * invraycov [P,6] zeros, radii [P] zeros, out_alpha_integrated [PN] ones, out_color_integrated [PN,3] zeros,
+ * out_coordinate2d [PN,2] zeros, out_sdf [PN] -1000, condition [P] zeros.  Five allocators as in the reference
+ * (geometry, binning, image, point, point-binning); the last two are asked for
+ * ed3dgs_integrate_point_bytes(PN, width, height) and ed3dgs_integrate_workspace_bytes(R, width, height) bytes.
+ */
+size_t ed3dgs_integrate_point_bytes(int PN, int width, int height);
+size_t ed3dgs_integrate_workspace_bytes(int R, int width, int height);
+int ed3dgs_integrate(
+    ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_alloc_fn binning_alloc, void *binning_user,
+    ed3dgs_alloc_fn image_alloc, void *image_user, ed3dgs_alloc_fn point_alloc, void *point_user,
+    ed3dgs_alloc_fn point_binning_alloc, void *point_binning_user, int PN, int P, int D, int M, const float *background,
+    int width, int height, const float *points3D, const float *means3D, const float *shs, const float *colors_precomp,
+    const float *opacities, const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx, float tan_fovy,
+    float kernel_size, int prefiltered, float *out_color, float *accum_alpha, float *invraycov, int *radii,
+    float *out_alpha_integrated, float *out_color_integrated, float *out_coordinate2d, float *out_sdf,
+    unsigned char *condition, int debug, void *stream);
+
+/*
  * simple_knn.distCUDA2 (submodules/simple-knn/simple_knn.cu:185-220, ext binding simple-knn/ext.cpp:15):
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest OTHER points (exact k-NN; a slot with no
  * neighbour counts FLT_MAX, as in the reference, so clouds of fewer than 4 points give huge / infinite values).

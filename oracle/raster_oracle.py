@@ -94,7 +94,7 @@ def forward(bg, means3D, colors_precomp, opacities, tongue_class, scales, rotati
             _p(proj), _p(campos), C.c_int(W), C.c_int(H), C.c_float(tanfovx), C.c_float(tanfovy),
             C.c_float(kernel_size), _p(g["clamped"]), _p(g["radii"]), _p(g["means2D"]), _p(g["view_points"]),
             _p(g["depths"]), _p(g["camera_planes"]), _p(g["ray_planes"]), _p(g["ts"]), _p(g["normals"]),
-            _p(g["cov3D"]), _p(g["rgb"]), _p(g["conic_opacity"]), _p(g["is_tongue"]), _p(g["tiles_touched"]))
+            _p(g["cov3D"]), _p(g["rgb"]), _p(g["conic_opacity"]), _p(g["is_tongue"]), _p(g["tiles_touched"]), None, None)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
     offsets = np.cumsum(g["tiles_touched"].astype(np.uint64)).astype(np.uint32)  # K2 inclusive scan
@@ -193,3 +193,86 @@ def backward(fw, bg, means3D, colors_precomp, scales, rotations, scale_modifier,
     return dict(dL_dmeans2D=f["mean2D"], dL_dcolors=f["colors"], dL_dopacity=dL_dopacity.reshape(P, 1),
                 dL_dmeans3D=dL_dmeans3D, dL_dcov3D=dL_dcov3D, dL_dsh=dL_dsh, dL_dscales=dL_dscales,
                 dL_drotations=dL_drot, inter=f, inter64=d)
+
+
+def integrate(bg, points3D, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+              viewmatrix, projmatrix, tanfovx, tanfovy, kernel_size, H, W, sh, degree, campos):
+    """CudaRasterizer::Rasterizer::integrate (CR/rasterizer_impl.cu:580-851) with the tensor shapes / fill values of
+    IntegrateGaussiansToPointsCUDA (DGR/rasterize_points.cu:273-392): K11 (preprocess with the inverse ray-space
+    covariance), K2-K5 for the Gaussians, K12 / K13 / sort / K5 for the query points, K14.  Returns a dict with the
+    outputs, the intermediate state and per-pixel / per-point decision margins (see ed3ref_integrate)."""
+    L = lib()
+    means3D = _f32(means3D); points3D = _f32(points3D)
+    P, PN = means3D.shape[0], points3D.shape[0]
+    sh = _f32(sh) if sh is not None and sh.size else None
+    colors_precomp = _f32(colors_precomp) if colors_precomp is not None and colors_precomp.size else None
+    scales = _f32(scales) if scales is not None and scales.size else None
+    rotations = _f32(rotations) if rotations is not None and rotations.size else None
+    cov3D_precomp = _f32(cov3D_precomp) if cov3D_precomp is not None and cov3D_precomp.size else None
+    M = sh.shape[1] if sh is not None else 0
+    opacities = _f32(opacities).reshape(-1)
+    view = _f32(viewmatrix).reshape(-1); proj = _f32(projmatrix).reshape(-1)
+    campos = _f32(campos).reshape(-1); bg = _f32(bg).reshape(-1)
+    H, W = int(H), int(W)
+    tanfovx, tanfovy = np.float32(tanfovx), np.float32(tanfovy)
+    focal_y = np.float32(H) / (np.float32(2.0) * tanfovy)
+    focal_x = np.float32(W) / (np.float32(2.0) * tanfovx)
+    g = dict(
+        clamped=np.zeros((P, 3), np.uint8), radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32),
+        view_points=np.zeros((P, 3), np.float32), depths=np.zeros(P, np.float32),
+        camera_planes=np.zeros((P, 6), np.float32), ray_planes=np.zeros((P, 2), np.float32),
+        ts=np.zeros(P, np.float32), normals=np.zeros((P, 3), np.float32), cov3D=np.zeros((P, 6), np.float32),
+        rgb=np.zeros((P, 3), np.float32), conic_opacity=np.zeros((P, 4), np.float32),
+        is_tongue=np.zeros(P, np.float32), tiles_touched=np.zeros(P, np.uint32),
+        invraycov=np.zeros((P, 6), np.float32), condition=np.zeros(P, np.uint8))
+    L.ed3ref_preprocess(
+        C.c_int(P), C.c_int(int(degree)), C.c_int(M), _p(means3D), _p(scales), C.c_float(scale_modifier),
+        _p(rotations), _p(opacities), None, _p(sh), _p(cov3D_precomp), _p(colors_precomp), _p(view),
+        _p(proj), _p(campos), C.c_int(W), C.c_int(H), C.c_float(tanfovx), C.c_float(tanfovy),
+        C.c_float(kernel_size), _p(g["clamped"]), _p(g["radii"]), _p(g["means2D"]), _p(g["view_points"]),
+        _p(g["depths"]), _p(g["camera_planes"]), _p(g["ray_planes"]), _p(g["ts"]), _p(g["normals"]),
+        _p(g["cov3D"]), _p(g["rgb"]), _p(g["conic_opacity"]), _p(g["is_tongue"]), _p(g["tiles_touched"]),
+        _p(g["invraycov"]), _p(g["condition"]))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    bit = int(L.ed3ref_higher_msb(C.c_uint32(T)))
+
+    def binned(n, keys_u, vals_u):
+        keys = np.zeros(n, np.uint64); lst = np.zeros(n, np.uint32); ranges = np.zeros((T, 2), np.uint32)
+        L.ed3ref_sort_pairs(C.c_int64(n), _p(keys_u), _p(vals_u), _p(keys), _p(lst), C.c_int(32 + bit))
+        L.ed3ref_identify_tile_ranges(C.c_int64(n), _p(keys), _p(ranges), C.c_int(T))
+        return lst, ranges
+
+    offsets = np.cumsum(g["tiles_touched"].astype(np.uint64)).astype(np.uint32)
+    R = int(offsets[-1]) if P else 0
+    keys_u = np.zeros(R, np.uint64); vals_u = np.zeros(R, np.uint32)
+    L.ed3ref_duplicate_with_keys(C.c_int(P), _p(g["means2D"]), _p(g["depths"]), _p(offsets), _p(g["radii"]),
+                                 C.c_int(W), C.c_int(H), _p(keys_u), _p(vals_u))
+    point_list, ranges = binned(R, keys_u, vals_u)
+    # query points
+    q = dict(points2D=np.zeros((PN, 2), np.float32), depths=np.zeros(PN, np.float32), tiles_touched=np.zeros(PN, np.uint32))
+    L.ed3ref_preprocess_points(C.c_int(PN), _p(points3D), _p(view), C.c_int(W), C.c_int(H), C.c_float(focal_x),
+                               C.c_float(focal_y), _p(q["points2D"]), _p(q["depths"]), _p(q["tiles_touched"]))
+    qoff = np.cumsum(q["tiles_touched"].astype(np.uint64)).astype(np.uint32)
+    NI = int(qoff[-1]) if PN else 0
+    qk = np.zeros(NI, np.uint64); qv = np.zeros(NI, np.uint32)
+    L.ed3ref_create_with_keys(C.c_int(PN), _p(q["points2D"]), _p(q["depths"]), _p(qoff), _p(q["tiles_touched"]),
+                              C.c_int(W), C.c_int(H), _p(qk), _p(qv))
+    qlist, qranges = binned(NI, qk, qv)
+    out = dict(
+        out_color=np.zeros((9, H, W), np.float32), accum_alpha=np.zeros((1, H, W), np.float32),
+        n_contrib=np.zeros((H, W), np.uint32), alpha_integrated=np.ones(PN, np.float32),
+        color_integrated=np.zeros((PN, 3), np.float32), coordinate2d=np.zeros((PN, 2), np.float32),
+        sdf=np.full(PN, -1000.0, np.float32), pix_margin=np.zeros((H, W), np.float32),
+        pt_margin=np.full(PN, 1e30, np.float32))
+    features = colors_precomp if colors_precomp is not None else g["rgb"]
+    L.ed3ref_integrate(
+        C.c_int(W), C.c_int(H), _p(ranges), _p(qranges), _p(point_list), _p(qlist), C.c_float(focal_x), C.c_float(focal_y),
+        _p(q["points2D"]), _p(g["means2D"]), _p(features), _p(g["ray_planes"]), _p(g["invraycov"]), _p(q["depths"]),
+        _p(g["ts"]), _p(g["conic_opacity"]), _p(g["condition"]), _p(bg), _p(out["accum_alpha"]), _p(out["n_contrib"]),
+        _p(out["out_color"]), _p(out["alpha_integrated"]), _p(out["color_integrated"]), _p(out["coordinate2d"]),
+        _p(out["sdf"]), _p(out["pix_margin"]), _p(out["pt_margin"]))
+    out.update(num_rendered=R, num_integrated=NI, ranges=ranges, point_list=point_list, point_valid=q["tiles_touched"] > 0,
+               points2D=q["points2D"], point_depths=q["depths"])
+    out.update(g)
+    return out

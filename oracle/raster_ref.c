@@ -294,10 +294,10 @@ static void cov3d_from_scale_rot(const float *scale, float mod, const float *rot
     cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
 }
 
-/* CR/forward.cu:77-264 (INTE=false) */
-static void cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy, float kernel_size,
-                         const float *cov3D, const float *view, float cov2D[3], float camera_plane[6], float normal[3],
-                         float ray_plane[2], float *coef)
+/* CR/forward.cu:77-264; inv6 != NULL is the INTE = true instantiation (:187-235).  Returns well_conditioned. */
+static int cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy, float kernel_size,
+                        const float *cov3D, const float *view, float cov2D[3], float camera_plane[6], float normal[3],
+                        float ray_plane[2], float *coef, float *inv6)
 {
     v3 t = xform4x3(mean, view);
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
@@ -349,6 +349,38 @@ static void cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, 
         m3 nJ = m3_cols(1 / t.z, 0.0f, -(t.x) / (t.z * t.z), 0.0f, 1 / t.z, -(t.y) / (t.z * t.z), t.x / l, t.y / l,
                         t.z / l);
         m3 nJ_inv = m3_cols(v2 + 1, -uv, 0, -uv, u2 + 1, 0, -txtz, -tytz, 0);
+        if (inv6) {
+            m3 inv_cov_ray;
+            if (well_conditioned) {
+                float ltz = u2 + v2 + 1;
+                m3 full = m3_scale(m3_cols(v2 + 1, -uv, txtz / l * ltz, -uv, u2 + 1, tytz / l * ltz, -txtz, -tytz, 1 / l * ltz),
+                                   t.z / (u2 + v2 + 1));
+                m3 T2 = m3_mul(Wm, m3_T(full));
+                inv_cov_ray = m3_mul(m3_mul(m3_T(T2), Vrk_inv), T2);
+            } else {
+                /* :204-232.  The reference stores this branch's result in a block-local `inv_cov_ray` that shadows the
+                   outer one (:219), so what it then scales and writes is an UNINITIALISED matrix; the value the branch
+                   computes is used here (documented deviation from undefined behaviour). */
+                m3 T2 = m3_mul(Wm, nJ);
+                m3 cov_ray = m3_mul(m3_mul(m3_T(T2), Vrk_inv), T2);
+                m3 cvec; float cval[3];
+                eig_sym3(cov_ray, cval, &cvec);
+                unsigned mid = cval[0] > cval[1] ? (cval[1] > cval[2] ? 2 : 1) : (cval[0] > cval[2] ? 2 : 0);
+                float lambda1 = cval[(mid + 1) % 3], lambda2 = cval[(mid + 2) % 3];
+                m3 nv;
+                for (int q = 0; q < 3; q++) {
+                    nv.m[0][q] = cvec.m[(mid + 1) % 3][q]; nv.m[1][q] = cvec.m[(mid + 2) % 3][q]; nv.m[2][q] = cvec.m[mid][q];
+                }
+                v3 r3 = v3_mk(nv.m[0][2], nv.m[1][2], nv.m[2][2]);
+                m3 c2d = m3_cols(1 / lambda1, 0, -r3.x / r3.z / lambda1, 0, 1 / lambda2, -r3.y / r3.z / lambda2,
+                                 -r3.x / r3.z / lambda1, -r3.y / r3.z / lambda2, 0);
+                inv_cov_ray = m3_mul(m3_mul(nv, c2d), m3_T(nv));
+            }
+            m3 sc = m3_cols(1 / focal_x, 0, 0, 0, 1 / focal_y, 0, 0, 0, 1);
+            inv_cov_ray = m3_mul(m3_mul(sc, inv_cov_ray), sc);
+            inv6[0] = inv_cov_ray.m[0][0]; inv6[1] = inv_cov_ray.m[0][1]; inv6[2] = inv_cov_ray.m[0][2];
+            inv6[3] = inv_cov_ray.m[1][1]; inv6[4] = inv_cov_ray.m[1][2]; inv6[5] = inv_cov_ray.m[2][2];
+        }
         float vbn = v3_dot(uvh_mn, uvh);
         float factor_normal = l / (u2 + v2 + 1);
         v3 plane = m3_mulv(nJ_inv, v3_divs(uvh_mn, fmaxf(vbn, 0.0000001f)));
@@ -366,6 +398,7 @@ static void cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, 
         v3 n = v3_normalize(cam_normal);
         normal[0] = n.x; normal[1] = n.y; normal[2] = n.z;
     }
+    return well_conditioned;
 }
 
 /* K10: CR/rasterizer_impl.cu:54-66 + CR/auxiliary.h:155-180 */
@@ -385,7 +418,8 @@ void ed3ref_preprocess(int P, int D, int M, const float *means, const float *sca
                        const float *campos, int W, int H, float tan_fovx, float tan_fovy, float kernel_size,
                        uint8_t *clamped, int32_t *radii, float *means2D, float *view_points, float *depths,
                        float *camera_planes, float *ray_planes, float *ts, float *normals, float *cov3Ds, float *rgb,
-                       float *conic_opacity, float *is_tongue, uint32_t *tiles_touched)
+                       float *conic_opacity, float *is_tongue, uint32_t *tiles_touched, float *invraycov /* [P][6] or NULL: K11 */,
+                       uint8_t *condition /* [P] or NULL */)
 {
     const float focal_y = H / (2.0f * tan_fovy); /* CR/rasterizer_impl.cu:291-292 */
     const float focal_x = W / (2.0f * tan_fovx);
@@ -403,8 +437,10 @@ void ed3ref_preprocess(int P, int D, int M, const float *means, const float *sca
         if (cov3D_precomp) cov3D = cov3D_precomp + 6 * idx;
         else { cov3d_from_scale_rot(scales + 3 * idx, scale_modifier, rotations + 4 * idx, cov3Ds + 6 * idx); cov3D = cov3Ds + 6 * idx; }
         float cov2D[3], coef;
-        cov2d_planes(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, cov2D,
-                     camera_planes + 6 * idx, normals + 3 * idx, ray_planes + 2 * idx, &coef);
+        int wc = cov2d_planes(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, cov2D,
+                              camera_planes + 6 * idx, normals + 3 * idx, ray_planes + 2 * idx, &coef,
+                              invraycov ? invraycov + 6 * idx : NULL);
+        if (condition) condition[idx] = (uint8_t)wc;   /* CR/forward.cu:373-376 */
         ts[idx] = sqrtf(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
         float cx = cov2D[0], cy = cov2D[1], cz = cov2D[2];
         float det = (cx * cz - cy * cy);
@@ -430,7 +466,7 @@ void ed3ref_preprocess(int P, int D, int M, const float *means, const float *sca
         conic_opacity[4 * idx] = conic[0]; conic_opacity[4 * idx + 1] = conic[1]; conic_opacity[4 * idx + 2] = conic[2];
         conic_opacity[4 * idx + 3] = opacities[idx] * coef;
         tiles_touched[idx] = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
-        is_tongue[idx] = tongue_class[idx];
+        is_tongue[idx] = tongue_class ? tongue_class[idx] : 0.f;
     }
 }
 
@@ -1093,4 +1129,206 @@ int ed3ref_eig_sym3(const float cov6[6], float val[3], float vec9[9])
     m3 E; int n = eig_sym3(V, val, &E);
     for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) vec9[3 * c + r] = E.m[c][r];
     return n;
+}
+
+
+/* ===================== point integration (mesh-extraction probe) ===================== */
+/* K12: CR/forward.cu:1027-1071.  Outputs zero-initialised by the caller. */
+void ed3ref_preprocess_points(int PN, const float *pts, const float *view, int W, int H, float focal_x, float focal_y,
+                              float *points2D, float *depths, uint32_t *tiles_touched)
+{
+    for (int i = 0; i < PN; i++) {
+        tiles_touched[i] = 0;
+        v3 pv = xform4x3(v3_mk(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), view);
+        if (pv.z <= 0.2f) continue;
+        float px = (float)(focal_x * pv.x / (pv.z + 0.0000001f) + W / 2.);
+        float py = (float)(focal_y * pv.y / (pv.z + 0.0000001f) + H / 2.);
+        if (px < 0 || px >= W || py < 0 || py >= H) continue;
+        depths[i] = sqrtf(pv.x * pv.x + pv.y * pv.y + pv.z * pv.z);
+        points2D[2 * i] = px; points2D[2 * i + 1] = py;
+        tiles_touched[i] = 1;
+    }
+}
+
+/* K13: CR/rasterizer_impl.cu:114-145 */
+void ed3ref_create_with_keys(int PN, const float *points2D, const float *depths, const uint32_t *offsets,
+                             const uint32_t *tiles_touched, int W, int H, uint64_t *keys, uint32_t *vals)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    for (int i = 0; i < PN; i++) {
+        if (tiles_touched[i] == 0) continue;
+        uint32_t off = (i == 0) ? 0 : offsets[i - 1];
+        int x = imin(gx - 1, imax(0, (int)(points2D[2 * i] / TILE)));
+        int y = imin(gy - 1, imax(0, (int)(points2D[2 * i + 1] / TILE)));
+        uint64_t key = (uint64_t)(y * gx + x);
+        key <<= 32;
+        uint32_t dbits; memcpy(&dbits, &depths[i], 4);
+        key |= dbits;
+        keys[off] = key; vals[off] = (uint32_t)i;
+    }
+}
+
+#define MAX_NUM_CONTRIBUTORS 512 /* CR/auxiliary.h:31 */
+#define MAX_NUM_PROJECTED 256    /* :32 */
+
+static float relgap(float v, float thr) { return fabsf(v - thr) / thr; }
+
+/* K14: CR/forward.cu:1109-1543, one pixel at a time (the reference's block-wide loops only share loads).
+   out_color: 9 planes (0-2 colour, 3 expected ray distance, 4 median, 6 maximal, 7 alpha, 8 number of projected points).
+   pix_margin / pt_margin (optional): smallest relative distance of any threshold decision taken for the pixel / point
+   from its threshold, so that a test can leave out the cases that a last-ulp difference would flip. */
+void ed3ref_integrate(int W, int H, const uint32_t *ranges, const uint32_t *point_ranges, const uint32_t *gaussian_list,
+                      const uint32_t *point_list, float focal_x, float focal_y, const float *points2D,
+                      const float *gaussians2D, const float *features, const float *ray_planes, const float *invraycov,
+                      const float *point_depths, const float *gaussian_depths, const float *conic_opacity,
+                      const uint8_t *condition, const float *bg, float *final_T, uint32_t *n_contrib, float *out_color,
+                      float *out_alpha_integrated, float *out_color_integrated, float *out_coordinate2d, float *out_sdf,
+                      float *pix_margin, float *pt_margin)
+{
+    (void)focal_x; (void)focal_y;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const size_t HW = (size_t)H * W;
+    static const float offx[5] = {0.0f, -0.5f, 0.5f, -0.5f, 0.5f}, offy[5] = {0.0f, -0.5f, -0.5f, 0.5f, 0.5f};
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const int tile = ty * gx + tx;
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            const uint32_t q0 = point_ranges[2 * tile], q1 = point_ranges[2 * tile + 1];
+            uint16_t *ids = (uint16_t *)malloc(sizeof(uint16_t) * MAX_NUM_CONTRIBUTORS * 4);
+            for (int ly = 0; ly < TILE; ly++)
+                for (int lx = 0; lx < TILE; lx++) {
+                    const int px = tx * TILE + lx, py = ty * TILE + ly;
+                    if (px >= W || py >= H) continue;
+                    const size_t pix = (size_t)py * W + px;
+                    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+                    float T = 1.0f, cT[5] = {1.f, 1.f, 1.f, 1.f, 1.f};
+                    float C[3] = {0, 0, 0}, Cd = 0, Cmed = 0, Cmax = 0, Ca = 0;
+                    float mid_dc = 0, mid_plane[2] = {0, 0}, mid_mean[2] = {0, 0};
+                    uint32_t contributor = 0, last = 0, n_local = 0;
+                    float marg = 1e30f;
+                    for (uint32_t i = r0; i < r1; i++) {
+                        contributor++;
+                        const uint32_t g = gaussian_list[i];
+                        const float *co = conic_opacity + 4 * g;
+                        const float dc = gaussian_depths[g];
+                        const float *dp = ray_planes + 2 * g, *xy = gaussians2D + 2 * g;
+                        int used = 0;
+                        for (int k = 0; k < 5; k++) {
+                            float dx = xy[0] - pfx - offx[k], dy = xy[1] - pfy - offy[k];
+                            float depth = dc + (dp[0] * dx + dp[1] * dy);
+                            float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                            if (power > 0.0f) continue;
+                            float alpha = minf(0.99f, co[3] * expf(power));
+                            marg = minf(marg, relgap(alpha, 1.0f / 255.0f));
+                            if (alpha < 1.0f / 255.0f) continue;
+                            float test_T = cT[k] * (1 - alpha);
+                            marg = minf(marg, relgap(test_T, 0.0001f));
+                            if (test_T < 0.0001f) continue;
+                            if (k == 0) for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * g + ch] * alpha * T;
+                            if (depth > Cmax) Cmax = depth;
+                            if (k == 0) {
+                                Ca += alpha * T;
+                                Cd += depth * alpha * T;
+                                marg = minf(marg, relgap(T, 0.5f));
+                                if (T > 0.5f) { Cmed = depth; mid_dc = dc; mid_plane[0] = dp[0]; mid_plane[1] = dp[1]; mid_mean[0] = xy[0]; mid_mean[1] = xy[1]; }
+                                T = test_T;
+                            }
+                            cT[k] = test_T;
+                            used = 1;
+                        }
+                        if (used) {
+                            last = contributor;
+                            ids[n_local] = (uint16_t)contributor;
+                            n_local++;
+                            if (n_local >= MAX_NUM_CONTRIBUTORS * 4) break;
+                        }
+                    }
+                    final_T[pix] = T;
+                    n_contrib[pix] = last;
+                    for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = C[ch] + T * bg[ch];
+                    out_color[3 * HW + pix] = Cd;
+                    out_color[4 * HW + pix] = Cmed;
+                    out_color[6 * HW + pix] = Cmax;
+                    out_color[7 * HW + pix] = Ca;
+                    if (pix_margin) pix_margin[pix] = marg;
+
+                    /* the pixel's points, in batches of MAX_NUM_PROJECTED (:1336-1536) */
+                    int proj_ids[MAX_NUM_PROJECTED];
+                    float proj_xy[MAX_NUM_PROJECTED][2], proj_depth[MAX_NUM_PROJECTED];
+                    uint32_t point_counter_last = 0;
+                    int total_projected = 0, point_done = 0;
+                    while (!point_done) {
+                        int num_projected = 0, exceed = 0;
+                        uint32_t point_counter = 0;
+                        for (uint32_t q = q0; q < q1; q++) {
+                            point_counter++;
+                            if (point_counter <= point_counter_last) continue;
+                            const uint32_t id = point_list[q];
+                            const float x = points2D[2 * id], y = points2D[2 * id + 1];
+                            if ((x >= (pfx - 0.5)) && (x < (pfx + 0.5)) && (y >= (pfy - 0.5)) && (y < (pfy + 0.5))) {
+                                if (num_projected >= MAX_NUM_PROJECTED) { exceed = 1; break; }
+                                proj_ids[num_projected] = (int)id; proj_xy[num_projected][0] = x; proj_xy[num_projected][1] = y;
+                                proj_depth[num_projected] = point_depths[id];
+                                num_projected++;
+                            }
+                        }
+                        point_counter_last = point_counter - 1;
+                        point_done = !exceed;
+                        total_projected += num_projected;
+                        float p_alpha[MAX_NUM_PROJECTED], p_T[MAX_NUM_PROJECTED], p_marg[MAX_NUM_PROJECTED];
+                        for (int k = 0; k < num_projected; k++) { p_alpha[k] = 0.f; p_T[k] = 1.f; p_marg[k] = 1e30f; }
+                        uint32_t num_iterated = 0;
+                        uint16_t second = 0;
+                        for (uint32_t i = r0; i < r1; i++) {
+                            num_iterated++;
+                            if (num_iterated > last) break;
+                            if (num_iterated != (uint32_t)ids[second]) continue;
+                            second++;
+                            const uint32_t g = gaussian_list[i];
+                            const float *co = conic_opacity + 4 * g, *dp = ray_planes + 2 * g, *xy = gaussians2D + 2 * g;
+                            const float dc = gaussian_depths[g];
+                            const float *c6 = invraycov + 6 * g;
+                            m3 M = m3_cols(c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]);
+                            for (int k = 0; k < num_projected; k++) {
+                                float dx = xy[0] - proj_xy[k][0], dy = xy[1] - proj_xy[k][1];
+                                float depth = dc + (dp[0] * dx + dp[1] * dy);
+                                float alpha;
+                                if (condition[g]) {
+                                    v3 du = v3_mk(dx, dy, dc - minf(proj_depth[k], depth));
+                                    float power = -0.5f * v3_dot(du, m3_mulv(M, du));
+                                    alpha = minf(0.99f, co[3] * expf(power));
+                                } else {
+                                    p_marg[k] = minf(p_marg[k], fabsf(proj_depth[k] - depth) / fmaxf(fabsf(depth), 1e-6f));
+                                    if (proj_depth[k] < depth) alpha = 0;
+                                    else {
+                                        v3 du = v3_mk(dx, dy, dc);
+                                        float power = -0.5f * v3_dot(du, m3_mulv(M, du));
+                                        alpha = minf(0.99f, co[3] * expf(power));
+                                    }
+                                }
+                                p_marg[k] = minf(p_marg[k], relgap(alpha, 1.0f / 255.0f));
+                                if (alpha < 1.0f / 255.0f) continue;
+                                float test_T = p_T[k] * (1 - alpha);
+                                p_alpha[k] += alpha * p_T[k];
+                                p_T[k] = test_T;
+                            }
+                        }
+                        for (int k = 0; k < num_projected; k++) {
+                            const int id = proj_ids[k];
+                            out_alpha_integrated[id] = p_alpha[k];
+                            for (int ch = 0; ch < 3; ch++) out_color_integrated[3 * id + ch] = C[ch] + T * bg[ch];
+                            out_coordinate2d[2 * id] = proj_xy[k][0]; out_coordinate2d[2 * id + 1] = proj_xy[k][1];
+                            if (proj_depth[k] > 0) {
+                                float dx = mid_mean[0] - proj_xy[k][0], dy = mid_mean[1] - proj_xy[k][1];
+                                float depth = mid_dc + (mid_plane[0] * dx + mid_plane[1] * dy);
+                                out_sdf[id] = depth - proj_depth[k];
+                            }
+                            if (pt_margin) pt_margin[id] = minf(p_marg[k], marg);
+                        }
+                    }
+                    out_color[8 * HW + pix] = (float)total_projected;
+                }
+            free(ids);
+        }
 }

@@ -58,18 +58,21 @@ def test_c2_forward_and_backward_parity_100k_1080p():
         assert v <= TOL_GRAD, (n, v)
 
 
-def test_c3_properties_200k_deform_on():
+@pytest.mark.parametrize("P,coord", [(200_000, False), (500_000, True)], ids=["C3-200k", "C5-500k-coord"])
+def test_properties_deform_on(P, coord):
+    """BASELINE.json configs[2] (200k) and the per-GPU item of configs[4] (500k Gaussians, SH degree 3, 1080p, full
+    deformation, depth + normal + coord outputs): size-independent properties."""
     _need_gpu()
     from diff_gaussian_rasterization import _C
     from ed3dgs_amd import synthetic as S
     from ed3dgs_amd.model import PIPE, SynthGaussianModel, default_hyper
     from gaussian_renderer import render
     dev = "cuda"
-    P, W, H = 200_000, 1920, 1080
+    W, H = 1920, 1080
     model = SynthGaussianModel(S.make_scene(P, seed=0), args=default_hyper(), device=dev)
     cam = S.make_cameras(8, W, H, seed=1, device=dev)[3].with_time(17 / 50)
     bg = torch.ones(3, device=dev)
-    kw = dict(kernel_size=0.0, require_coord=False, require_depth=True, iter=20000, num_down_emb_c=30, num_down_emb_f=30)
+    kw = dict(kernel_size=0.0, require_coord=coord, require_depth=True, iter=20000, num_down_emb_c=30, num_down_emb_f=30)
     _C.KEEP_LAST = True
     try:
         pkg = render(cam, model, PIPE, bg, **kw)
