@@ -361,6 +361,41 @@ def test_python_surface_matches_reference_names_and_errors():
     assert list(inspect.signature(gr.render_tongue).parameters) == sig
 
 
+def test_new_entry_points_validate_arguments_without_a_gpu():
+    """Argument checks come before any HIP call: bad sizes / null pointers return ED3DGS_ERR_INVALID and set the message;
+    the Python mirrors of simple_knn / integrate keep the reference's names, signatures and error texts."""
+    import ctypes as C
+    import inspect
+    from ed3dgs_amd import _lib
+    L = _lib.lib()
+    assert L.ed3dgs_knn_workspace_bytes(C.c_int(200_000)) > 200_000 * 16
+    assert L.ed3dgs_knn_mean_dist2(C.c_int(-1), None, None, None, C.c_size_t(0), None) < 0 and b"bad P" in L.ed3dgs_last_error()
+    assert L.ed3dgs_knn_mean_dist2(C.c_int(0), None, None, None, C.c_size_t(0), None) == 0
+    assert L.ed3dgs_knn_mean_dist2(C.c_int(5), None, None, None, C.c_size_t(0), None) < 0 and b"null pointer" in L.ed3dgs_last_error()
+    assert L.ed3dgs_knn_neighbours(C.c_int(5), C.c_int(7), None, None, None, None, C.c_size_t(0), None) < 0 and b"K must be 20" in L.ed3dgs_last_error()
+    assert L.ed3dgs_integrate_point_bytes(C.c_int(1000), C.c_int(64), C.c_int(48)) > 1000 * 24
+    assert L.ed3dgs_integrate_workspace_bytes(C.c_int(1000), C.c_int(64), C.c_int(48)) >= 1000 * 32 + 64 * 48 * 36
+    from simple_knn._C import distCUDA2
+    with pytest.raises(RuntimeError, match="GPU"):
+        distCUDA2(torch.zeros(4, 3))
+    import diff_gaussian_rasterization as dgr
+    import gaussian_renderer as gr
+    assert list(inspect.signature(dgr._C.integrate_gaussians_to_points).parameters) == [
+        "background", "points3D", "means3D", "colors", "opacity", "scales", "rotations", "scale_modifier", "cov3D_precomp",
+        "view2gaussian_precomp", "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "kernel_size", "subpixel_offset",
+        "image_height", "image_width", "sh", "degree", "campos", "prefiltered", "debug"]     # DGR/rasterize_points.cu:273-297
+    assert list(inspect.signature(dgr.GaussianRasterizer.integrate).parameters) == [
+        "self", "points3D", "means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations",
+        "cov3D_precomp", "view2gaussian_precomp"]                                          # DGR __init__.py:245
+    assert list(inspect.signature(gr.integrate).parameters) == [
+        "points3D", "viewpoint_camera", "pc", "pipe", "bg_color", "kernel_size", "loaded_iter", "scaling_modifier",
+        "override_color", "num_down_emb_c", "num_down_emb_f"]                               # gaussian_renderer/__init__.py:551
+    with pytest.raises(RuntimeError, match="points3D must have dimensions"):
+        dgr._C.integrate_gaussians_to_points(torch.ones(3), torch.zeros(5), torch.zeros(4, 3), torch.Tensor([]), torch.zeros(4, 1),
+                                             torch.zeros(4, 3), torch.zeros(4, 4), 1.0, torch.Tensor([]), torch.Tensor([]), torch.eye(4),
+                                             torch.eye(4), 1.0, 1.0, 0.0, None, 8, 8, torch.zeros(4, 16, 3), 3, torch.zeros(3), False, False)
+
+
 def test_deform_network_state_dict_keys_and_row_counts():
     from scene.deformation import deform_network
     a = DR.Args()
