@@ -1294,15 +1294,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             f32x16 acc = zero_acc();
 #pragma unroll
                             for (int kt = 0; kt < NT; kt++) acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
+                            // the 16 W3 values of this lane are fetched from LDS in one go, ahead of the epilogue's VALU
+                            // work: read-wait-MFMA per k-slot (what the compiler emits for the plain loop) is a chain of
+                            // 16 LDS latencies, as long as the tile's 64 big MFMAs
+                            const float *f3 = wb + NT * TS + 32 * h + (lane & 3);
+                            float w3v[16];
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++) w3v[kk] = f3[kk * 64];
+                            __builtin_amdgcn_sched_barrier(0);
                             float z[1][16];
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                             if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
-                            const float *f3 = wb + NT * TS + 32 * h + (lane & 3);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int kk = 0; kk < 16; kk++)
-                                yn = __builtin_amdgcn_mfma_f32_4x4x1f32(f3[kk * 64], z[0][kk], yn, 0, 0, 0);
+                                yn = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk], z[0][kk], yn, 0, 0, 0);
                             GPIPE_ADVANCE();
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
@@ -1446,25 +1454,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
-                    if (h == 0) {
-                        for (int j = 0; j < nk; j++) {
-                            float v = 0.f;
-                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
-                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
-                            gy[0][j] = v * hc;
-                        }
+                    // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
+                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
+                    const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
+                    const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
+                    float vo[4], vs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const size_t ix = (size_t)g * nk + min(j, nk - 1);
+                        vo[j] = po[uo ? ix : (size_t)g];
+                        vs[j] = ps[us ? ix : (size_t)g];
                     }
+                    const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) gy[0][j] = (h == 0 && j < nk) ? vo[j] * mo + vs[j] * ms : 0.f;
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < 6; cc++) {
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
-                        float4 v = make_float4(0, 0, 0, 0);
-                        if (feat < shw) {
-                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                        }
+                        // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
+                        const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
-                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                        gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
+                        gy[ot][kk0 + 2] = to.z * mo4 + tu.z * ms4; gy[ot][kk0 + 3] = to.w * mo4 + tu.w * ms4;
                     }
                 }
 #pragma unroll 1
@@ -1642,25 +1658,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
-                    if (h == 0) {
-                        for (int j = 0; j < nk; j++) {
-                            float v = 0.f;
-                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
-                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
-                            gy[0][j] = v * hc;
-                        }
+                    // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
+                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
+                    const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
+                    const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
+                    float vo[4], vs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const size_t ix = (size_t)g * nk + min(j, nk - 1);
+                        vo[j] = po[uo ? ix : (size_t)g];
+                        vs[j] = ps[us ? ix : (size_t)g];
                     }
+                    const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) gy[0][j] = (h == 0 && j < nk) ? vo[j] * mo + vs[j] * ms : 0.f;
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < 6; cc++) {
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
-                        float4 v = make_float4(0, 0, 0, 0);
-                        if (feat < shw) {
-                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                        }
+                        // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
+                        const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
-                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                        gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
+                        gy[ot][kk0 + 2] = to.z * mo4 + tu.z * ms4; gy[ot][kk0 + 3] = to.w * mo4 + tu.w * ms4;
                     }
                 }
 #pragma unroll 1
@@ -1777,25 +1801,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
-                    if (h == 0) {
-                        for (int j = 0; j < nk; j++) {
-                            float v = 0.f;
-                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
-                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
-                            gy[0][j] = v * hc;
-                        }
+                    // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
+                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
+                    const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
+                    const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
+                    float vo[4], vs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const size_t ix = (size_t)g * nk + min(j, nk - 1);
+                        vo[j] = po[uo ? ix : (size_t)g];
+                        vs[j] = ps[us ? ix : (size_t)g];
                     }
+                    const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) gy[0][j] = (h == 0 && j < nk) ? vo[j] * mo + vs[j] * ms : 0.f;
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < 6; cc++) {
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
-                        float4 v = make_float4(0, 0, 0, 0);
-                        if (feat < shw) {
-                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                        }
+                        // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
+                        const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
-                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                        gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
+                        gy[ot][kk0 + 2] = to.z * mo4 + tu.z * ms4; gy[ot][kk0 + 3] = to.w * mo4 + tu.w * ms4;
                     }
                 }
                 XSplit gys[OTMAX];
@@ -1920,25 +1952,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
-                    if (h == 0) {
-                        for (int j = 0; j < nk; j++) {
-                            float v = 0.f;
-                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
-                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
-                            gy[0][j] = v * hc;
-                        }
+                    // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
+                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
+                    const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
+                    const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
+                    float vo[4], vs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const size_t ix = (size_t)g * nk + min(j, nk - 1);
+                        vo[j] = po[uo ? ix : (size_t)g];
+                        vs[j] = ps[us ? ix : (size_t)g];
                     }
+                    const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) gy[0][j] = (h == 0 && j < nk) ? vo[j] * mo + vs[j] * ms : 0.f;
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < 6; cc++) {
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
-                        float4 v = make_float4(0, 0, 0, 0);
-                        if (feat < shw) {
-                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                        }
+                        // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
+                        const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
-                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
+                        gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
+                        gy[ot][kk0 + 2] = to.z * mo4 + tu.z * ms4; gy[ot][kk0 + 3] = to.w * mo4 + tu.w * ms4;
                     }
                 }
                 XSplitN<NP> gys[OTMAX];
