@@ -1285,7 +1285,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         // k-slot kk, so B is z as it stands, and A (W3[i = lane & 3][that feature]) is a 4-address gather
                         // from the head's ordinary 32x32x2 fragment.  8 cycles per step instead of 64 on a tile with 4
                         // useful rows.
-                        f32x4 yn = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 yn = {0.f, 0.f, 0.f, 0.f}, yn2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
                         for (int nt = 0; nt < NT; nt++) {
                             const float *wb = PIPE_CUR();
@@ -1308,16 +1308,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                             if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
                             __builtin_amdgcn_sched_barrier(0);
+                            // two interleaved accumulation chains: a dependent 4x4x1 MFMA waits out the previous one's passes
 #pragma unroll
-                            for (int kk = 0; kk < 16; kk++)
+                            for (int kk = 0; kk < 16; kk += 2) {
                                 yn = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk], z[0][kk], yn, 0, 0, 0);
+                                yn2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk + 1], z[0][kk + 1], yn2, 0, 0, 0);
+                            }
                             GPIPE_ADVANCE();
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
                         float yo[4];
 #pragma unroll
-                        for (int i = 0; i < 4; i++) yo[i] = (yn[i] + __shfl_xor(yn[i], 32) + b3[i]) * hc;  // the two feature halves
+                        for (int i = 0; i < 4; i++) { const float ys = yn[i] + yn2[i]; yo[i] = (ys + __shfl_xor(ys, 32) + b3[i]) * hc; }  // the two feature halves
                         if (h == 0) {
                             if (k == 0) { cx[0] += yo[0]; cx[1] += yo[1]; cx[2] += yo[2]; }
                             else if (k == 1) { cs[0] += yo[0]; cs[1] += yo[1]; cs[2] += yo[2]; }
