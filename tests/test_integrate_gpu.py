@@ -146,3 +146,25 @@ def test_renderer_level_integrate_runs_on_a_model():
     with pytest.raises(Exception):
         from diff_gaussian_rasterization import GaussianRasterizer
         GaussianRasterizer(None).integrate(pts, pts, pts, pts)      # neither SHs nor colours
+
+
+def test_no_visible_gaussians():
+    """Every Gaussian behind the camera: num_rendered 0, the image is the background, valid points integrate nothing."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    inp = util.scene_inputs(200, 64, 48)
+    view = inp["viewmatrix"].numpy().T
+    c2w = np.linalg.inv(view)
+    behind = (np.concatenate([np.random.default_rng(0).uniform(-1, 1, (200, 2)), -np.full((200, 1), 5.0), np.ones((200, 1))], 1) @ c2w.T)[:, :3]
+    pts = (np.array([[0.0, 0.0, 3.0, 1.0], [0.2, -0.1, 6.0, 1.0]]) @ c2w.T)[:, :3].astype(np.float32)
+    d = lambda t: t.cuda().contiguous()
+    e = torch.Tensor([])
+    out = _C.integrate_gaussians_to_points(
+        d(inp["bg"]), torch.from_numpy(pts).cuda(), torch.from_numpy(behind.astype(np.float32)).cuda(), e, d(inp["opacities"]),
+        d(inp["scales"]), d(inp["rotations"]), 1.0, e, e, d(inp["viewmatrix"]), d(inp["projmatrix"]), inp["tanfovx"],
+        inp["tanfovy"], 0.0, None, 48, 64, d(inp["shs"]), 3, d(inp["campos"]), False, False)
+    assert out[0] == 0 and not out[6].any()
+    assert torch.equal(out[1][:3], torch.ones(3, 48, 64, device="cuda")) and not out[1][3:8].any()
+    assert float(out[1][8].sum()) == 2.0
+    assert torch.equal(out[2], torch.zeros(2, device="cuda")) and torch.equal(out[3], torch.ones(2, 3, device="cuda"))
+    assert (out[5] < 0).all()          # sdf = 0 - depth: no surface in front of the point
