@@ -2721,11 +2721,25 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                     d = mfma_b3(gyh, gyl, w3b[bi * 64 + lane], w3b[(bi + 1) * 64 + lane], d);
                 }
             } else {
-                constexpr int UNG = WIDE ? 4 : KS3;   // the 24-step product fully unrolled pushes the wide body into scratch
-#pragma unroll UNG
-                for (int kk = 0; kk < KS3; kk++) {
-                    const float wv = WIDE ? w3s[(2 * kk + h) * HJ_W + (2 * pmi + t) * 32 + c] : w3f[t][WIDE ? 0 : kk];
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], wv, d, 0, 0, 0);  // rows past nk: zeros
+                if constexpr (WIDE) {
+                    // operands of 8 k-steps are read from LDS together, then the 8 (dependent) MFMAs run back to back: a
+                    // read / wait / MFMA sequence per step leaves the pipe idle for an LDS latency every 64 cycles
+#pragma unroll 1
+                    for (int k0 = 0; k0 < KS3; k0 += 8) {
+                        float ga8[8], wb8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            ga8[q] = gs[c * LDG + 2 * (k0 + q) + h];                                   // rows past nk: zeros
+                            wb8[q] = w3s[(2 * (k0 + q) + h) * HJ_W + (2 * pmi + t) * 32 + c];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) d = __builtin_amdgcn_mfma_f32_32x32x2f32(ga8[q], wb8[q], d, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KS3; kk++)
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], w3f[t][kk], d, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -2779,8 +2793,32 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
             }
         } else {
         // dW2 patch: k-step kk multiplies Gaussian rows f(kk, h); dW3 tile(s): rows 2kk + h
-        constexpr int UNR = WIDE ? 4 : 16;   // the wide instantiation is at the register limit: fewer operand reads in flight
-#pragma unroll UNR
+        if constexpr (WIDE) {
+            // operand reads of TWO k-slots together (10 LDS reads), then their 12 MFMAs; see the g_z product above
+#pragma unroll 2
+            for (int k0 = 0; k0 < 16; k0 += 2) {
+                float b0[2], b1[2], zb[2], g0[2], g1[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int kk = k0 + q, rowf = (kk & 3) + 8 * (kk >> 2) + 4 * h, row = 2 * kk + h;
+                    b0[q] = as[rowf * HJ_W + (2 * pni) * 32 + c]; b1[q] = as[rowf * HJ_W + (2 * pni + 1) * 32 + c];
+                    zb[q] = zs[row * HJ_W + wave * 32 + c];
+                    g0[q] = gs[row * LDG + c]; g1[q] = gs[row * LDG + 32 + c];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int kk = k0 + q;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[0][kk], b0[q], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[0][kk], b1[q], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[1][kk], b0[q], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gz[1][kk], b1[q], acc[1][1], 0, 0, 0);
+                    acc3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[q], zb[q], acc3[0], 0, 0, 0);
+                    acc3[MT3 - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[q], zb[q], acc3[MT3 - 1], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
         for (int kk = 0; kk < 16; kk++) {
             const int rowf = (kk & 3) + 8 * (kk >> 2) + 4 * h;
             const float b0 = as[rowf * HJ_W + (2 * pni) * 32 + c], b1 = as[rowf * HJ_W + (2 * pni + 1) * 32 + c];
@@ -2799,6 +2837,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
                 // a 32x32x2 tile would spend 64 cycles on 4 useful rows, this spends 8
                 acc3n = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[row * LDG + (lane & 3)], zb, acc3n, 0, 0, 0);
             }
+        }
         }
         }
         if (DW3 && tid < nk) {
