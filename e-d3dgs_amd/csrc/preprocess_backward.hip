@@ -106,26 +106,25 @@ __device__ inline void cov3d_backward(v3 scale, float mod, float4 rot, const flo
 #undef MT
 }
 
-__global__ void __launch_bounds__(256) preprocess_backward_kernel(
-    int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
+// one Gaussian; the SH gradient row (3 M floats) goes to sh_row -- an LDS row of the caller, written out coalesced
+__device__ __forceinline__ void preprocess_backward_body(
+    int idx, int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     const float *__restrict__ cov3D_precomp, const float *__restrict__ view, const float *__restrict__ proj,
     const float *__restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, float kernel_size,
     const float *__restrict__ rec, const float *__restrict__ cov3Ds, const uint8_t *__restrict__ clamped,
     const float *__restrict__ grec, const float *__restrict__ grec_coord, bool has_colors_precomp, bool q1_reference,
     float hW, float hH, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dcolor, float *__restrict__ dL_dopacity,
-    float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
+    float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D, float *__restrict__ sh_row,
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
     if (!(radii[idx] > 0)) {
 #pragma unroll
         for (int i = 0; i < 3; i++) { dL_dmean2D[3 * idx + i] = 0.f; dL_dcolor[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
         dL_dopacity[idx] = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
-        if (shs) for (int i = 0; i < 3 * M; i++) dL_dsh[(size_t)idx * M * 3 + i] = 0.f;
+        if (shs) for (int i = 0; i < 3 * M; i++) sh_row[i] = 0.f;
         if (scales) {
 #pragma unroll
             for (int i = 0; i < 3; i++) dL_dscale[3 * idx + i] = 0.f;
@@ -354,7 +353,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     dmean = dmean + mk3(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z);
     if (shs && !has_colors_precomp) {
         v3 ds = sh_backward(D, M, mean, mk3(campos[0], campos[1], campos[2]), shs + (size_t)idx * M * 3, clamped[idx],
-                            g_color, dL_dsh + (size_t)idx * M * 3);
+                            g_color, sh_row);
         dmean = dmean + ds;
     }
     dL_dmean3D[3 * idx] = dmean.x; dL_dmean3D[3 * idx + 1] = dmean.y; dL_dmean3D[3 * idx + 2] = dmean.z;
@@ -362,6 +361,40 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
         v3 sc = mk3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
         float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
         cov3d_backward(sc, scale_modifier, q, dcov, dL_dscale + 3 * idx, dL_drot + 4 * idx);
+    }
+}
+
+// thread = Gaussian.  dL_dsh is the largest output (192 B per Gaussian at degree 3); written per thread it is 48
+// stores of 4 bytes at a 192-byte lane stride.  The rows are staged in LDS (odd row stride: conflict-free) and the
+// block writes its 256 rows -- contiguous in memory -- as one coalesced stream.
+__global__ void __launch_bounds__(256) preprocess_backward_kernel(
+    int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
+    const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
+    const float *__restrict__ cov3D_precomp, const float *__restrict__ view, const float *__restrict__ proj,
+    const float *__restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, float kernel_size,
+    const float *__restrict__ rec, const float *__restrict__ cov3Ds, const uint8_t *__restrict__ clamped,
+    const float *__restrict__ grec, const float *__restrict__ grec_coord, bool has_colors_precomp, bool q1_reference,
+    float hW, float hH, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dcolor, float *__restrict__ dL_dopacity,
+    float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
+    float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
+{
+    extern __shared__ float sh_rows[];
+    const int w3 = 3 * M, ld = w3 | 1;                // odd stride
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool staged = shs && !has_colors_precomp;   // the case in which every Gaussian's SH row is written
+    float *row = staged ? sh_rows + threadIdx.x * ld : (dL_dsh ? dL_dsh + (size_t)min(idx, P - 1) * w3 : nullptr);
+    if (idx < P)
+        preprocess_backward_body(idx, P, D, M, means, radii, shs, scales, rotations, scale_modifier, cov3D_precomp, view, proj,
+                                 campos, h_x, h_y, tan_fovx, tan_fovy, kernel_size, rec, cov3Ds, clamped, grec, grec_coord,
+                                 has_colors_precomp, q1_reference, hW, hH, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D,
+                                 dL_dcov3D, row, dL_dscale, dL_drot);
+    if (!staged) return;
+    __syncthreads();
+    const int first = blockIdx.x * blockDim.x, nrow = min((int)blockDim.x, P - first);
+    float *out = dL_dsh + (size_t)first * w3;
+    for (int e = threadIdx.x; e < nrow * w3; e += blockDim.x) {
+        const int r = e / w3, cc = e - r * w3;
+        out[e] = sh_rows[r * ld + cc];
     }
 }
 
@@ -374,7 +407,8 @@ void launch_preprocess_backward(int P, int D, int M, const float *means, const i
                                 float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                                 float *dL_dscale, float *dL_drot, hipStream_t s)
 {
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, radii, shs,
+    const size_t lds = (shs && !colors_precomp) ? (size_t)256 * ((3 * M) | 1) * sizeof(float) : 0;   // SH gradient rows
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), lds, s, P, D, M, means, radii, shs,
                        scales, rotations, scale_modifier, cov3D_precomp, view, proj, campos, focal_x, focal_y, tan_fovx,
                        tan_fovy, kernel_size, g.rec, g.cov3D, g.clamped, grec, grec_coord, colors_precomp, q1_reference,
                        0.5f * W, 0.5f * H, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
