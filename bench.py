@@ -339,7 +339,7 @@ def main():
     K = {  # slot -> (kernel name, algorithmic MAC per Gaussian, products per MAC, matrix pipe)
         2: ({"exact_split": "deform_forward_b3_kernel<4,3>", "bf16x3": "deform_forward_b3_kernel<4,2>", "fp32_mfma": "deform_forward_pipe_kernel<4>"}[mode], mac_all, npr),
         3: ({"exact_split": "deform_dgrad_kept_bn_kernel<4,3>", "bf16x3": "deform_dgrad_kept_b3_kernel<4>", "fp32_mfma": "deform_dgrad_kept_kernel<4>"}[mode], mac_all, npr),
-        5: ("deform_wgrad_kernel (dW1)", mac_trunk, 1),
+        5: ("deform_dw1_kernel", mac_trunk, 1),
         6: ({"exact_split": "deform_head_wgrad_kernel<true,false,true>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false,true>"}[mode], mac_wide, 3 if mode == "bf16x3" else 1),
         7: ({"exact_split": "deform_head_wgrad_narrow_bn_kernel<3>", "bf16x3": "deform_head_wgrad_kernel<false,true,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false,true>"}[mode], mac_narrow, npr),
     }

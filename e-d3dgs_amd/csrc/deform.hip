@@ -3161,6 +3161,87 @@ __global__ void __launch_bounds__(256) deform_dw3_wide_kernel(HeadWgradArgs a)
     if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
+// dW1[:, TD:] = g_hid^T emb and db1 = sum g_hid (W = 128, E = 32) as a streaming kernel of their own: 256 KB of g_hid per 512
+// Gaussians against 0.5 MFLOP -- the generic slab kernel above (register staging, two barriers per slab) moves it at
+// ~2 TB/s.  Here the (g_hid, emb) slabs come in by LDS-DMA, double-buffered, one barrier per slab; wave w owns the 32
+// features w*32.. of dW1 (all 32 embedding columns), operands of 8 k-steps are read together ahead of their MFMAs.
+struct Dw1Job {
+    const float *G, *E;      // g_hid [P, 128], embedding [P, 32]
+    float *dW, *db;          // dW1 + TD (row stride ldw), db1
+    int ldw;
+};
+struct Dw1Args {
+    int P, njobs;
+    int blk_begin[3];
+    Dw1Job job[2];
+};
+__global__ void __launch_bounds__(256) deform_dw1_kernel(Dw1Args a)
+{
+    extern __shared__ float hj_lds[];
+    constexpr int GS = 32 * 128, ES = 32 * 32, BUF = GS + ES;
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    const Dw1Job &J = a.job[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P;
+    const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int p0 = split * chunk, p1 = min(P, p0 + chunk);
+    if (p0 >= p1) return;
+    const int nslab = (p1 - p0 + 31) / 32;
+    auto dma = [&](int slab, int buf) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int piece = i * 4 + wave;                    // 1 KB = 2 rows of g_hid
+            const int row = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.G + (size_t)min(r0 + row, p1 - 1) * 128 + col),
+                                             (__attribute__((address_space(3))) void *)(hj_lds + buf * BUF + piece * 256), 16, 0, 0);
+        }
+        const int row = wave * 8 + (lane >> 3), col = (lane & 7) * 4;   // 1 KB = 8 rows of the embedding
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.E + (size_t)min(r0 + row, p1 - 1) * 32 + col),
+                                         (__attribute__((address_space(3))) void *)(hj_lds + buf * BUF + GS + wave * 256), 16, 0, 0);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float bsum = 0.f;
+    dma(0, 0);
+    __syncthreads();
+    for (int slab = 0; slab < nslab; slab++) {
+        const int buf = slab & 1;
+        if (slab + 1 < nslab) dma(slab + 1, buf ^ 1);
+        const float *gs = hj_lds + buf * BUF, *es = gs + GS;
+        const int rows = min(32, p1 - (p0 + slab * 32));       // rows past the range hold a re-read row
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int row = 2 * (k0 + q) + h;
+                const float g = gs[row * 128 + wave * 32 + c];
+                av[q] = row < rows ? g : 0.f;
+                bv[q] = es[row * 32 + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+                bsum += av[q];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int fi = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        atomicAdd(J.dW + (size_t)fi * J.ldw + c, acc[r]);
+    }
+    const float v = bsum + __shfl_xor(bsum, 32);
+    if (h == 0) atomicAdd(J.db + wave * 32 + c, v);
+}
+
 struct ZeroArgs {
     float *p[4];
     size_t n[4];
@@ -3583,6 +3664,10 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 }
         };
         const bool both = cfg->use_stage[0] && cfg->use_stage[1];
+        const bool dw1_stream = cfg->W == 128 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_DW1_GENERIC");
+        Dw1Args dw1;
+        std::memset(&dw1, 0, sizeof dw1);
+        dw1.P = cfg->P;
         std::vector<HeadJob> hjobs;
         for (int st = 0; st < 2; st++) {
             if (!cfg->use_stage[st]) continue;
@@ -3609,6 +3694,12 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 add_job(w.GZ[st] + k * PW, nullptr, cfg->W, cfg->W, 1.f, w.A[st], cfg->W, cfg->W, gparams[st] + pl.W2[k],
                         cfg->W, gparams[st] + pl.b2[k]);  // dW2 / db2
             }
+            if (dw1_stream) {
+                Dw1Job J;
+                J.G = w.GHID[st]; J.E = embedding; J.dW = gparams[st] + pl.W1 + cfg->TD; J.db = gparams[st] + pl.b1;
+                J.ldw = cfg->TD + cfg->E;
+                dw1.job[dw1.njobs++] = J;
+            } else
             add_job(w.GHID[st], nullptr, cfg->W, cfg->W, 1.f, embedding, cfg->E, cfg->E, gparams[st] + pl.W1 + cfg->TD,
                     cfg->TD + cfg->E, gparams[st] + pl.b1);  // dW1[:, TD:] and db1 (= g_hb)
         }
@@ -3625,6 +3716,12 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     const int max_split = std::max(1, (cfg->P + 4 * WG_ROWS - 1) / (4 * WG_ROWS));
     const size_t wg_lds = (size_t)2 * WG_ROWS * 256 * sizeof(float);  // two buffers of 32 rows x (Mp + Np <= 256)
     const bool pw5 = prof_start(ED3DGS_PROF_DEFORM_WGRAD_TRUNK, s);
+    if (dw1.njobs) {
+        int nb = 0;
+        for (int q = 0; q < dw1.njobs; q++) { dw1.blk_begin[q] = nb; nb += std::max(1, std::min((cfg->P + 127) / 128, 512 / dw1.njobs)); }
+        dw1.blk_begin[dw1.njobs] = nb;
+        hipLaunchKernelGGL(deform_dw1_kernel, dim3(nb), dim3(256), (size_t)2 * (32 * 128 + 32 * 32) * sizeof(float), s, dw1);
+    }
     for (int j0 = 0; j0 < nj_total; j0 += MAXJOBS) {
         WgradArgs wa;
         std::memset(&wa, 0, sizeof wa);
