@@ -1458,7 +1458,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
                     // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
-                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // reads ONE dummy element -- the same address in every lane -- and is multiplied by zero), so that they are issued together and waited for
                     // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
                     const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
                     const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
@@ -1466,8 +1466,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const size_t ix = (size_t)g * nk + min(j, nk - 1);
-                        vo[j] = po[uo ? ix : (size_t)g];
-                        vs[j] = ps[us ? ix : (size_t)g];
+                        vo[j] = po[uo ? ix : (size_t)0];
+                        vs[j] = ps[us ? ix : (size_t)0];
                     }
                     const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
 #pragma unroll
@@ -1478,8 +1478,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
                         // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
                         const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
-                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
-                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb);
                         const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
                         gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
@@ -1662,7 +1662,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
                     // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
-                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // reads ONE dummy element -- the same address in every lane -- and is multiplied by zero), so that they are issued together and waited for
                     // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
                     const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
                     const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
@@ -1670,8 +1670,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const size_t ix = (size_t)g * nk + min(j, nk - 1);
-                        vo[j] = po[uo ? ix : (size_t)g];
-                        vs[j] = ps[us ? ix : (size_t)g];
+                        vo[j] = po[uo ? ix : (size_t)0];
+                        vs[j] = ps[us ? ix : (size_t)0];
                     }
                     const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
 #pragma unroll
@@ -1682,8 +1682,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
                         // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
                         const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
-                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
-                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb);
                         const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
                         gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
@@ -1805,7 +1805,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
                     // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
-                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // reads ONE dummy element -- the same address in every lane -- and is multiplied by zero), so that they are issued together and waited for
                     // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
                     const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
                     const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
@@ -1813,8 +1813,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const size_t ix = (size_t)g * nk + min(j, nk - 1);
-                        vo[j] = po[uo ? ix : (size_t)g];
-                        vs[j] = ps[us ? ix : (size_t)g];
+                        vo[j] = po[uo ? ix : (size_t)0];
+                        vs[j] = ps[us ? ix : (size_t)0];
                     }
                     const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
 #pragma unroll
@@ -1825,8 +1825,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
                         // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
                         const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
-                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
-                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb);
                         const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
                         gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
@@ -1956,7 +1956,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
                 if (k < 4) {
                     // up to 8 upstream values per Gaussian: unconditional loads from clamped addresses (an absent tensor
-                    // reads a dummy element and is multiplied by zero), so that they are issued together and waited for
+                    // reads ONE dummy element -- the same address in every lane -- and is multiplied by zero), so that they are issued together and waited for
                     // once -- a load / wait pair per value is a chain of up to 8 HBM latencies per head
                     const bool uo = add_out && d.g[k], us = add_sub && d.gs[k];
                     const float *po = uo ? d.g[k] : d.emb, *ps = us ? d.gs[k] : d.emb;   // d.emb: P * E floats, set in every backward
@@ -1964,8 +1964,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const size_t ix = (size_t)g * nk + min(j, nk - 1);
-                        vo[j] = po[uo ? ix : (size_t)g];
-                        vs[j] = ps[us ? ix : (size_t)g];
+                        vo[j] = po[uo ? ix : (size_t)0];
+                        vs[j] = ps[us ? ix : (size_t)0];
                     }
                     const float mo = uo ? hc : 0.f, ms = us ? hc : 0.f;
 #pragma unroll
@@ -1976,8 +1976,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
                         // unconditional 16-byte loads (absent tensor / padded feature: a dummy row times zero), all 12 in flight
                         const bool uo4 = add_out && d.g[4] && feat < shw, us4 = add_sub && d.gs[4] && feat < shw;
-                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
-                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb + (size_t)g * d.E);
+                        const float4 to = *reinterpret_cast<const float4 *>(uo4 ? d.g[4] + (size_t)g * shw + feat : d.emb);
+                        const float4 tu = *reinterpret_cast<const float4 *>(us4 ? d.gs[4] + (size_t)g * shw + feat : d.emb);
                         const float mo4 = uo4 ? hc : 0.f, ms4 = us4 ? hc : 0.f;
                         const int ot = cc >> 2, kk0 = 4 * (cc & 3);
                         gy[ot][kk0] = to.x * mo4 + tu.x * ms4; gy[ot][kk0 + 1] = to.y * mo4 + tu.y * ms4;
