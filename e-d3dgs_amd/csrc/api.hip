@@ -292,8 +292,11 @@ int ed3dgs_rasterize_backward(
     float *grec = nullptr, *grec_coord = nullptr;
     obtain(wc, grec, (size_t)P * GREC, 128);
     if (require_coord) obtain(wc, grec_coord, (size_t)P * GREC, 128);
-    const size_t zero_bytes = (size_t)P * GREC * sizeof(float) * (require_coord ? 2 : 1);
-    if (!check_hip(hipMemsetAsync(grec, 0, zero_bytes, s), "memset gradient records")) return ED3DGS_ERR_HIP;
+    // one memset from the first record to the end of the last one: obtain() aligns grec_coord to 128 B, so for odd P the
+    // two arrays are NOT adjacent (64-byte records) and 2*P*64 bytes from grec would stop short of Gaussian P-1's
+    // coord record
+    char *zero_end = (char *)((require_coord ? grec_coord : grec) + (size_t)P * GREC);
+    if (!check_hip(hipMemsetAsync(grec, 0, (size_t)(zero_end - (char *)grec), s), "memset gradient records")) return ED3DGS_ERR_HIP;
 
     if (R > 0) {
         const bool pb = prof_start(ED3DGS_PROF_TILE_BACKWARD, s);
