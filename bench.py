@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the MI355X-native E-D3DGS hot path.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1 without a torchrun environment (WORLD_SIZE unset): this process makes NO GPU call and starts
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...` as a child,
+  relays rank 0's JSON line and exits with the child's code.  Under torchrun (WORLD_SIZE set) it is one rank of N.
 
 A "step" = one pass of the hot path over one (camera, frame) item: gaussian_renderer.render() forward (fused
 deformation MLP -> activations -> preprocess -> binning -> tile forward) + backward (tile backward -> per-Gaussian
@@ -35,6 +37,14 @@ WORKLOADS = {
                name="C3: 200k Gaussians, 8 cams x 50 timesteps, 1080p, deform MLP W=128 D=1, depth+normal (FTT)"),
     "C2": dict(P=100_000, W=1920, H=1080, cams=1, frames=1, deform=False,
                name="C2: 100k Gaussians, 1 cam 1080p, static, depth+normal (FTT)"),
+    "C4": dict(P=200_000, W=1100, H=1604, cams=15, frames=300, deform=True,
+               name="C4: 200k Gaussians, 15 train cams (16 views, cam00 held out) x 300 timesteps, NeRSemble-shaped 1100x1604, "
+                    "deform MLP W=128 D=1, depth+normal (FTT)"),
+    "C5": dict(P=500_000, W=1920, H=1080, cams=8, frames=150, deform=True,
+               name="C5: 500k Gaussians, SH degree 3, 8 cams x 150 frames, 1080p, full deform, depth+normal (FTT) training step; "
+                    "render_fps = all outputs (TTT)"),
+    "C1": dict(P=10_000, W=400, H=400, cams=1, frames=1, deform=False,
+               name="C1: 10k Gaussians, 1 cam 400x400, 1 timestep, no deformation (plumbing / CPU-baseline point)"),
     "tiny": dict(P=10_000, W=400, H=400, cams=2, frames=4, deform=True, name="tiny: 10k Gaussians 400x400 (plumbing)"),
 }
 
@@ -124,8 +134,9 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(wl):
-    """PyTorch-CPU autograd restatement (oracle/) of the same step on a bounded sample, all usable host cores."""
+def cpu_baseline(wl, full=False):
+    """PyTorch-CPU autograd restatement (oracle/) of the same step on a bounded sample, all usable host cores
+    (full=True: every tile, nothing extrapolated -- the C1 point of SURVEY 8d)."""
     from ed3dgs_amd import synthetic as S
     from ed3dgs_amd.model import default_hyper
     from oracle import deformation_torch as DT
@@ -152,7 +163,7 @@ def cpu_baseline(wl):
         xyz_f, ls_f, rot_f, op_f, sh_f = xyz, ls, rot, op, sh
     scales = torch.exp(ls_f); rots = torch.nn.functional.normalize(rot_f); opac = torch.sigmoid(op_f)
     T = ((wl["W"] + 15) // 16) * ((wl["H"] + 15) // 16)
-    stride = max(1, T // 400)
+    stride = 1 if full else max(1, T // 400)
     subset = list(range(stride // 2, T, stride))
     pp = TR.preprocess(xyz_f, scales, rots, opac, sh_f, cam.world_view_transform, cam.full_proj_transform,
                        cam.camera_center, wl["W"], wl["H"], math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0.0, 1.0, 3)
@@ -183,23 +194,116 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-points", action="store_true", help="also time the CPU restatement at C1 (in full) and at the C2 point (SURVEY 8d); minutes of CPU work")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed extra passes in the MLP's other multiply modes (for profiles)")
     ap.add_argument("--dp-grads", action="store_true", help="also all-reduce the gradients every step (data-parallel training; not the headline configuration)")
-    a = ap.parse_args()
+    ap.add_argument("--rehearse-launcher", action="store_true",
+                    help="NO GPU work and NO measurement: run the launcher / rendezvous / sharding / collectives / JSON plumbing "
+                         "with a stub step (CPU, gloo) -- what tests/test_bench_launcher_cpu.py drives")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(a, argv):
+    """--gpus N > 1 outside torchrun: start N ranks as a fresh child process tree BEFORE this process touches the GPU (a
+    process that has initialised HIP must never exec or be duplicated into ranks), relay the child's output (rank 0 prints
+    the JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ED3DGS_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("launching %d ranks: %s" % (a.gpus, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def hbm_ceiling(device, nbytes=1 << 30, reps=10):
+    """On-box HBM ceiling, measured in the untimed section (state it beside the 8 TB/s spec): a device-to-device
+    copy (read N + write N) and a stream triad a = b + s*c (read 2N + write N) over 1-GiB arrays, hipEvent-timed."""
+    n = nbytes // 4
+    x, y, z = (torch.empty(n, dtype=torch.float32, device=device).normal_() for _ in range(3))
+    out = {}
+    for name, fn, moved in (("copy", lambda: z.copy_(x), 2 * nbytes), ("triad", lambda: torch.add(x, y, alpha=3.0, out=z), 3 * nbytes)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.synchronize()
+        out[name] = moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del x, y, z
+    torch.cuda.empty_cache()
+    return out
+
+
+def percentiles(v):
+    v = sorted(v)
+    q = lambda f: v[min(len(v) - 1, max(0, int(round(f * (len(v) - 1)))))]
+    return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "min": v[0], "max": v[-1], "n": len(v)}
+
+
+def rehearse(a, D):
+    """Launcher rehearsal (no GPU, no measurement): every piece of the multi-rank harness around a stub step."""
+    import torch.distributed as dist
+    rank, world, local = D.init()
+    wl = WORKLOADS[a.workload]
+    n_items = wl["cams"] * wl["frames"]
+    mine = D.shard_items(max(n_items, world), rank, world)
+    inflight = []
+    D.barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        stats = torch.tensor([float(mine[k % len(mine)] % n_items), 0.0, 1.0])
+        if inflight:
+            inflight.pop().wait()
+        inflight.append(D.allreduce_sum_async(stats))
+    while inflight:
+        last = inflight.pop().wait()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, "cpu")
+    counts = torch.zeros(world); counts[rank] = a.steps
+    D.allreduce_sum_(counts)
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the launcher (stub step, no GPU work) -- not a measurement", "value": None,
+                          "rehearsal": True, "n_gpus": world, "gpus_arg": a.gpus, "steps": a.steps, "warmup": a.warmup,
+                          "backend": dist.get_backend() if dist.is_initialized() else None, "items_per_rank": counts.tolist(),
+                          "last_step_ranks_counted": float(last[2]), "seconds": dt,
+                          "launched_by_bench": bool(os.environ.get("ED3DGS_BENCH_LAUNCHED"))}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))            # nothing above this line touches the GPU
     from ed3dgs_amd import dist as D
+    if a.rehearse_launcher:
+        env_world = int(os.environ.get("WORLD_SIZE", "1"))
+        if a.gpus != env_world:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, env_world))
+        return rehearse(a, D)
     from ed3dgs_amd import _lib
     rank, world, local = D.init()
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the torchrun environment has WORLD_SIZE=%d -- refusing to report a line "
+                         "whose n_gpus is not what was asked for" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    local = local % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks may share one GPU (gloo)
+    shared_gpu = world > torch.cuda.device_count()         # rehearsal on a 1-GPU box: ranks share the card (gloo)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     L = _lib.lib()
@@ -211,6 +315,7 @@ def main():
     n_items = wl["cams"] * wl["frames"]
     my_items = D.shard_items(max(n_items, world), rank, world)
     item_at = lambda k: my_items[k % len(my_items)] % n_items
+    ceiling = hbm_ceiling(device) if rank == 0 else None
 
     # ---- untimed: warm-up + algorithmic-byte bookkeeping of the items the timed region will visit ----
     _C.KEEP_LAST = True
@@ -244,12 +349,16 @@ def main():
     torch.cuda.synchronize(); D.barrier()
     log("timed region")
     L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint((1 << dom) | 2))
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]   # step boundaries on the launch stream
     t0 = time.perf_counter()
+    marks[0].record()
     for k in range(a.steps):
         step(item_at(k))
+        marks[k + 1].record()
     step.drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
     slot_ms, slot_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(slot_ms, slot_n)
     # K6, K7, deform fwd, deform dgrad, deform wgrad (+ its three launches): timed-region events where taken, else the
@@ -313,13 +422,20 @@ def main():
     bytes_k6 = 68.0 * mean(reff) + 56.0 * HW + 8.0 * T
     k6_ms, k7_ms = avg_ms[0], avg_ms[1]
     ach = bytes_k7 / (k7_ms * 1e-3) / 1e9 if k7_ms > 0 else 0.0
-    pmc = {}
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(prof):
+    # HBM traffic per launch: NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes); read from the
+    # newest committed summary of such passes over this same command, and labelled as such (`traffic_source`)
+    pmc, traffic_source = {}, None
+    for prof_name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        prof = os.path.join(ROOT, "profiles", prof_name)
+        if not os.path.exists(prof):
+            continue
         try:
             pj = json.load(open(prof))
             if pj.get("workload") == a.workload:
                 pmc = pj.get("hbm_bytes_per_launch", {})
+                traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (committed file, not "
+                                  "collected by this run)" % (prof_name, pj.get("command", "python bench.py")))
+                break
         except Exception:
             pmc = {}
     # deformation MLP, algorithmic flops per Gaussian with the per-frame temporal row hoisted (SURVEY 8d counts the
@@ -358,7 +474,7 @@ def main():
         kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-               "traffic": pmc.get("render_backward_kernel<false,true>"),
+               "traffic": pmc.get("render_backward_kernel<false,true>"), "traffic_source": traffic_source,
                "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1],
                "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
@@ -368,7 +484,7 @@ def main():
         eq = tfl(mac, avg_ms[dom])
         peak = MFMA_BF16_PEAK_TFLOPS if pr > 1 else MFMA_F32_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": nm, "achieved": eq * pr, "peak": peak, "unit": "TFLOP/s", "frac": eq * pr / peak,
-                "traffic": pmc.get(nm.split(" ")[0]),
+                "traffic": pmc.get(nm.split(" ")[0]), "traffic_source": traffic_source,
                 "algorithmic_flops_per_launch": 2.0 * mac * wl["P"], "executed_matrix_flops_per_launch": 2.0 * mac * wl["P"] * pr,
                 "fp32_equivalent_TFLOPs": eq, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
                 "note": ("dominant kernel of the step by time.  Algorithmic flops = 2 * %d MAC per Gaussian (fp32 multiplies); " % mac) +
@@ -383,6 +499,13 @@ def main():
         "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "step_ms": dict(percentiles(step_ms), source="rank 0, hipEvent marks at the step boundaries of the timed region, on the launch stream"),
+        "frames_per_s": world * a.steps / dt,
+        "ranks": {"world": world, "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                  "rccl_ranks": world if (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
+                  "items_per_rank": [a.steps] * world, "gpus_shared": bool(shared_gpu),
+                  "launched_by_bench": bool(os.environ.get("ED3DGS_BENCH_LAUNCHED"))},
+        "hbm_ceiling_measured_GBps": dict(ceiling, spec=HBM_PEAK_GBPS, note="1-GiB device-to-device copy and stream triad on this box, untimed section; `peak` in the rooflines stays the 8 TB/s spec"),
         "config": {"workload": wl["name"], "gaussians": wl["P"], "resolution": [wl["W"], wl["H"]],
                    "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step" + ("; + bucketed gradient all-reduce (--dp-grads)" if a.dp_grads else ""),
                    "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
@@ -407,6 +530,15 @@ def main():
             res["cpu_baseline"] = cpu_baseline(wl)
         except Exception as ex:  # the baseline is a reported extra; a failure must not lose the GPU measurement
             res["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        if a.cpu_baseline_points:
+            pts = {}
+            for name in ("C1", "C2"):
+                log("cpu baseline point", name)
+                try:
+                    pts[name] = cpu_baseline(WORKLOADS[name], full=(name == "C1"))
+                except Exception as ex:
+                    pts[name] = {"value": None, "error": repr(ex)}
+            res["cpu_baseline_points"] = pts
     print(json.dumps(res))
 
 

@@ -1,0 +1,56 @@
+"""bench.py --gpus N must really span N ranks (VERDICT r1 #2 / ADVICE r1: `--gpus` was parsed and never read).  Driven here
+on the CPU: `python bench.py --gpus 2 --rehearse-launcher` with no torchrun environment must start two ranks itself
+(torch.distributed.run child, gloo), shard, run the per-step collective and print ONE line with n_gpus = 2.  The rehearsal
+has a stub step and reports no measurement (value null); the real path needs a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_gpus_2_launches_two_ranks_without_external_torchrun():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1",
+                        "--workload", "tiny", "--rehearse-launcher"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gpus_arg"] == 2 and d["launched_by_bench"] is True
+    assert d["rehearsal"] is True and d["value"] is None   # never mistakable for a measurement
+    assert d["backend"] == "gloo" and d["items_per_rank"] == [6.0, 6.0] and d["last_step_ranks_counted"] == 2.0
+    assert d["steps"] == 6 and d["warmup"] == 1
+
+
+def test_gpus_must_match_the_torchrun_world():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
+                        "--workload", "tiny", "--rehearse-launcher"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_single_rank_rehearsal_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "0", "--workload", "C4",
+                        "--rehearse-launcher"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["launched_by_bench"] is False and d["items_per_rank"] == [3.0]
+
+
+def test_workloads_cover_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    W = bench.WORKLOADS
+    assert W["C3"]["P"] == 200_000 and (W["C3"]["W"], W["C3"]["H"]) == (1920, 1080) and W["C3"]["cams"] * W["C3"]["frames"] == 400
+    assert W["C4"]["P"] == 200_000 and (W["C4"]["W"], W["C4"]["H"]) == (1100, 1604) and W["C4"]["cams"] * W["C4"]["frames"] == 4500
+    assert W["C5"]["P"] == 500_000 and W["C5"]["cams"] * W["C5"]["frames"] == 1200
+    assert bench.parse_args([]).workload == "C3" and bench.parse_args([]).gpus == 1

@@ -22,6 +22,7 @@ TOL_IMG = 1e-4
 TOL_GRAD = 5e-5      # backward kernels alone: oracle backward fed with the HIP forward's saved state
 TOL_GRAD_E2E = 2e-3  # forward+backward end to end (see test_backward_parity_c1 docstring)
 MARGIN = 2e-5
+MAX_MASKED_FRAC = 1e-3  # measured 2.8e-4 .. 1.0e-3 over the suite's configurations (printed per test)
 
 
 def _need_gpu():
@@ -57,7 +58,8 @@ def _check_images(fw, out, variant):
     (_, color, coord, mcoord, alpha, tongue, normal, depth, mdepth) = [o.cpu().numpy() if torch.is_tensor(o) else o for o in out[:9]]
     good = fw["margin"] >= MARGIN
     frac_bad = 1.0 - good.mean()
-    assert frac_bad < 5e-3, frac_bad
+    print("masked (threshold-marginal) pixel fraction: %.2e" % frac_bad)
+    assert frac_bad <= MAX_MASKED_FRAC, frac_bad
     errs = {}
     errs["color"] = util.rel_linf(color, fw["color"], good)
     errs["alpha"] = util.rel_linf(alpha, fw["alpha"], good)
@@ -149,7 +151,8 @@ def test_backward_parity_c1(variant, ks):
     # pixels with a blend decision within rounding of its threshold get no upstream gradient on either side
     # (see test_backward_ragged_sizes)
     good = torch.from_numpy((fw["margin"] >= MARGIN).astype(np.float32))
-    assert good.mean() > 0.99
+    print("masked (threshold-marginal) pixel fraction: %.2e" % float(1 - good.mean()))
+    assert float(1 - good.mean()) <= MAX_MASKED_FRAC
     for k in grads:
         grads[k] = grads[k] * good
     bw_e2e = util.oracle_backward(inp, fw, grads, variant)
@@ -198,7 +201,8 @@ def test_backward_ragged_sizes(variant, W, H):
     # that pair in one implementation and skip it in the other (exp2 vs expf): a 1/255-sized term.  Such pixels get a
     # zero upstream gradient on both sides, as the forward tests leave them out of the image comparison.
     good = torch.from_numpy((fw["margin"] >= MARGIN).astype(np.float32))
-    assert good.mean() > 0.99
+    print("masked (threshold-marginal) pixel fraction: %.2e" % float(1 - good.mean()))
+    assert float(1 - good.mean()) <= MAX_MASKED_FRAC
     for k in grads:
         grads[k] = grads[k] * good
     out, sv = util.hip_forward_raw(inp, variant)

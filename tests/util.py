@@ -83,3 +83,55 @@ def rel_linf(a, b, mask=None):
         d = d[..., mask] if d.ndim > mask.ndim else d[mask]
     scale = max(np.abs(b).max(), 1e-30)
     return d.max() / scale if d.size else 0.0
+
+
+GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+
+
+def zero_unused_grads(grads, variant):
+    rc, rd = VARIANTS[variant]
+    if not rc:
+        grads["coord"].zero_(); grads["mcoord"].zero_()
+    if not rd:
+        grads["depth"].zero_(); grads["mdepth"].zero_()
+    if not (rc or rd):
+        grads["normal"].zero_()
+    return grads
+
+
+def mask_marginal(grads, fw, margin):
+    """Pixels whose blend decision sits within `margin` of a threshold get no upstream gradient on either side; returns
+    the masked gradients and the excluded pixel fraction."""
+    good = torch.from_numpy((fw["margin"] >= margin).astype(np.float32))
+    return {k: v * good for k, v in grads.items()}, float(1.0 - good.mean())
+
+
+def oracle_state_from_hip(fw, out, sv):
+    """The oracle forward's dict with the HIP forward's saved per-pixel state substituted (kernel-level backward checks)."""
+    fw_hip = dict(fw)
+    fw_hip.update(alpha=out[4].cpu().numpy(), normal=out[6].cpu().numpy(), n_contrib=sv["n_contrib"],
+                  accum_coord=sv["accum_coord"], accum_depth=sv["accum_depth"], normal_length=sv["normal_length"])
+    return fw_hip
+
+
+def hip_backward_raw(inp, out, grads, variant, device="cuda", debug=False, colors_precomp=None, cov3D_precomp=None):
+    """Calls _C.rasterize_gaussians_backward with the 13-tuple `out` of hip_forward_raw; returns {name: numpy}."""
+    from diff_gaussian_rasterization import _C
+    rc, rd = VARIANTS[variant]
+    d = lambda t: t.to(device).contiguous()
+    e = torch.Tensor([])
+    use_cov = cov3D_precomp is not None
+    res = _C.rasterize_gaussians_backward(
+        d(inp["bg"]), d(inp["means3D"]), out[9], e if colors_precomp is None else d(colors_precomp),
+        e if use_cov else d(inp["scales"]), e if use_cov else d(inp["rotations"]), inp["scale_modifier"],
+        d(cov3D_precomp) if use_cov else e, d(inp["viewmatrix"]), d(inp["projmatrix"]), inp["tanfovx"], inp["tanfovy"],
+        inp["kernel_size"], d(grads["color"]), d(grads["coord"]), d(grads["mcoord"]), d(grads["depth"]),
+        d(grads["mdepth"]), d(grads["alpha"]), d(grads["normal"]), out[6],
+        e if colors_precomp is not None else d(inp["shs"]), inp["sh_degree"], d(inp["campos"]), out[10], out[0], out[11],
+        out[12], out[4], rc, rd, debug)
+    return {n: t.cpu().numpy() for n, t in zip(GRAD_NAMES, res)}
+
+
+def grad_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
