@@ -8,9 +8,16 @@
  *
  * PARITY STATUS: "parity unpinned by the reference" -- the reference holds no golden vectors, KATs or
  * tests for this path and its CUDA sources cannot be built or run in this pipeline (no nvcc, no NVIDIA
- * GPU).  This restatement is pinned instead by (see tests/): hand-derived known answers, float64 finite
- * differences of its own forward, an independent PyTorch-autograd restatement (oracle/torch_raster.py),
- * and structural invariants.
+ * GPU).  This restatement is pinned instead by (tests/test_oracle_cpu.py, tests/test_oracle_pins_cpu.py):
+ *   - hand-derived known answers (single Gaussian, alpha clamp / thresholds, mip coefficient, ordering + median, opaque
+ *     stack, culls, quirk Q1 at kernel_size 0.3) and structural invariants;
+ *   - its eigen-solver against a second, independent Python restatement (oracle/eig_ql_ref.py): bit-identical;
+ *   - an independent PyTorch-autograd restatement (oracle/torch_raster.py) of forward + every returned gradient
+ *     (incl. dL_dmeans2D x / y / abs-grad z, dL_dcolors, dL_dcov3D, the precomputed-colour / -covariance variant) on
+ *     FFF / FTT / TFT / TTT at kernel_size 0 and 0.3: the fp64 build of this file (-DED3REF_FP64) agrees to < 1e-6, this
+ *     fp32 build to < 1e-5 (images) / < 5e-4 (gradients; < 1e-5 once pixels with T_final < 1e-2 are left out -- the
+ *     reference's restart from T_final = 1 - alpha_out amplifies fp32 rounding by 1 / T_final);
+ *   - fp64 central differences of its own forward against its K7 / K8 / K9 (< 1e-7 with a converged eigen-solver).
  *
  * Every function cites the reference file:line it follows.  Arithmetic is fp32 with the same operand
  * order and the same float/double promotions as the C++ expressions of the reference (double literals such
@@ -21,6 +28,22 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+typedef float f32_t;         /* the 32-bit type by name (depth bits of the sort keys), whatever `float` means below */
+#ifdef ED3REF_FP64
+/* libraster_ref64.so: THE SAME TEXT with every fp32 quantity carried in fp64 (arrays, arguments, arithmetic).  It is
+ * not a statement about the reference's results -- those are fp32 -- but a tool for the tests: with rounding out of the
+ * way, (1) central differences of this forward check the hand-derived backward (K7 / K8 / K9) to ~1e-7, and (2) the
+ * independent autograd restatement (oracle/torch_raster.py, fp64) must agree with it to ~1e-9, so structural
+ * disagreements cannot hide under fp32 noise.  oracle/raster_oracle64.py is its ctypes front-end. */
+#define float double
+#define fabsf fabs
+#define sqrtf sqrt
+#define fmaxf fmax
+#define fminf fmin
+#define expf exp
+#define ceilf ceil
+#endif
 
 #define TILE 16              /* CR/config.h:16-17 BLOCK_X = BLOCK_Y = 16 */
 #define CHUNK 256            /* CR/auxiliary.h:19 BLOCK_SIZE */
@@ -33,6 +56,9 @@ static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.3153
                                -1.0925484305920792f, 0.5462742152960396f};
 static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+/* bits of the fp32 depth that form the low half of a sort key (CR/rasterizer_impl.cu:99-103) */
+static uint32_t depth_bits(float d) { f32_t f = (f32_t)d; uint32_t b; memcpy(&b, &f, 4); return b; }
 
 typedef struct { float x, y, z; } v3;
 typedef struct { float m[3][3]; } m3; /* m[c][r], as glm::mat3 */
@@ -136,10 +162,16 @@ static void get_rect(float px, float py, int max_radius, int gx, int gy, int rmi
  * Follows glm_modification::findEigenvaluesSymReal, CR/auxiliary.h:217-401 (1-based indexing kept through
  * the accessor macros so the control flow can be compared against the reference line by line). ---- */
 static int feq(float x, float y, float eps) { return fabsf(x - y) <= eps; }           /* :189-192 */
+/* Convergence threshold of the eigen-solver: the reference's ABSOLUTE 1e-7 (CR/auxiliary.h:203,238).  Tests may lower it
+ * (ed3ref_set_eig_epsilon) to run the same code with a CONVERGED solver -- used only to separate the solver's truncation
+ * from everything else (tests/test_oracle_pins_cpu.py); every parity comparison runs at the reference's value. */
+static float g_eig_epsilon = 0.0000001f;
+void ed3ref_set_eig_epsilon(double e) { g_eig_epsilon = (float)e; }
+double ed3ref_get_eig_epsilon(void) { return (double)g_eig_epsilon; }
 static float transfer_sign(float v, float s) { return (s >= 0) ? fabsf(v) : -fabsf(v); } /* :195-198 */
 static float pythag(float a, float b)                                                  /* :201-214 */
 {
-    const float epsilon = 0.0000001f;
+    const float epsilon = g_eig_epsilon;
     float absa = fabsf(a), absb = fabsf(b);
     if (absa > absb) { absb /= absa; absb *= absb; return absa * sqrtf(1.0f + absb); }
     if (feq(absb, 0.0f, epsilon)) return 0.0f;
@@ -155,7 +187,7 @@ static int eig_sym3(m3 cov, float val[3], m3 *vec)
     for (int r = 0; r < N; r++) for (int c = 0; c < N; c++) a[r * N + c] = cov.m[c][r];
     int l, k, j, i;
     float scale, hh, h, g, f;
-    const float epsilon = 0.0000001f;
+    const float epsilon = g_eig_epsilon;
     for (i = N; i >= 2; i--) {
         l = i - 1; h = scale = 0;
         if (l > 1) {
@@ -480,7 +512,7 @@ void ed3ref_duplicate_with_keys(int P, const float *means2D, const float *depths
             uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
             int rmin[2], rmax[2];
             get_rect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], gx, gy, rmin, rmax);
-            uint32_t dbits; memcpy(&dbits, &depths[idx], 4);
+            uint32_t dbits = depth_bits(depths[idx]);
             for (int y = rmin[1]; y < rmax[1]; y++)
                 for (int x = rmin[0]; x < rmax[0]; x++) {
                     uint64_t key = (uint64_t)(y * gx + x);
@@ -1162,7 +1194,7 @@ void ed3ref_create_with_keys(int PN, const float *points2D, const float *depths,
         int y = imin(gy - 1, imax(0, (int)(points2D[2 * i + 1] / TILE)));
         uint64_t key = (uint64_t)(y * gx + x);
         key <<= 32;
-        uint32_t dbits; memcpy(&dbits, &depths[i], 4);
+        uint32_t dbits = depth_bits(depths[i]);
         key |= dbits;
         keys[off] = key; vals[off] = (uint32_t)i;
     }

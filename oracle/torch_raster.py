@@ -5,10 +5,24 @@ BASELINE.json configs[0] / north_star): preprocess (CR/forward.cu:23-545), binni
 and the tile compositing rule (CR/forward.cu:672-821) are written with differentiable torch ops, so torch.autograd
 supplies the backward.  It is (a) an independent cross-check of oracle/raster_ref.c (forward values and gradients)
 and (b) the timed CPU baseline of bench.py.  Differences from the C restatement, by construction:
-  * the 3x3 symmetric eigen-decomposition uses torch.linalg.eigh instead of the reference's truncated QL solver
-    (CR/auxiliary.h:217-401), so plane / normal terms agree only to the solver's own tolerance (~1e-4 rel);
+  * the inverse of the 3D covariance.  The reference forms it from a TRUNCATED eigen-solver (glm's tred2 / tqli with
+    absolute 1e-7 thresholds, CR/auxiliary.h:217-401): at covariance eigenvalues of ~1e-3 its eigenvectors stop ~1e-4..1e-3
+    short of convergence, so the reference's plane / normal terms deviate SYSTEMATICALLY from exact linear algebra (measured:
+    up to 2e-3 on unit normals, 1e-3 on ray planes; the fp32 and fp64 builds of the solver agree with each other to 5e-6).
+    No exact method -- eigh or the closed-form spectrum of S R -- can therefore agree with the reference below ~1e-3.
+    Two modes: `sigma_inv=None` uses torch.linalg.eigh (exact algebra: the CPU baseline of bench.py, and the loose
+    cross-check); `sigma_inv=(P,3,3)` takes the truncated solver's inverse as DATA (the solver itself is pinned separately,
+    tests/test_oracle_pins_cpu.py: an independent Python restatement + numpy) and differentiates through it with the
+    perturbation rule d(S^-1) = -S^-1 dS S^-1 -- the rule the reference's K8 applies to its truncated inverse
+    (CR/backward.cu:333-336) -- so that everything downstream is an independent autograd check at rounding level;
+  * the alpha clamp min(0.99, w G) is straight-through in the backward, as in the reference (CR/backward.cu:852,978: dL_dG =
+    w dL_dalpha whether or not the clamp was active);
   * quirk Q1 (CR/rasterizer_impl.cu:576) is NOT reproduced: autograd differentiates the true mip coefficient, which
     is what oracle.raster_oracle.backward(reference_q1=False) computes.
+Extra leaves (`extra=`) expose the gradients autograd does not name: an NDC offset of the 2D mean (dL_dmeans2D.xy,
+CR/backward.cu:1002-1003), an offset of the final per-Gaussian colour (dL_dcolors) and of the six covariance entries
+(dL_dcov3D); the abs-grad column dL_dmeans2D.z (CR/backward.cu:1005-1006) is summed from the per-pair dL/dG that
+`render(..., keep_pairs=True)` retains.
 """
 import math
 
@@ -40,10 +54,33 @@ def eval_sh(deg, sh, dirs):
     return res + 0.5
 
 
+class _TruncatedInverse(torch.autograd.Function):
+    """S^-1 taken as data (the reference's truncated solver's value); backward = the perturbation rule
+    dL/dS = -S^-T (dL/dS^-1) S^-T that CR/backward.cu:333-336 applies to that same truncated inverse."""
+
+    @staticmethod
+    def forward(ctx, Sigma, Sinv):
+        ctx.save_for_backward(Sinv)
+        return Sinv.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (Sinv,) = ctx.saved_tensors
+        St = Sinv.transpose(1, 2)
+        return -(St @ g @ St), None
+
+
+def cov6_to_mat(c):
+    return torch.stack([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 3], c[:, 4], c[:, 2], c[:, 4], c[:, 5]], 1).reshape(-1, 3, 3)
+
+
 def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,
-               kernel_size, scale_modifier, sh_degree):
-    """Returns a dict of per-Gaussian screen-space quantities (differentiable) + integer binning data."""
+               kernel_size, scale_modifier, sh_degree, sigma_inv=None, cov3D_precomp=None, colors_precomp=None, extra=None):
+    """Returns a dict of per-Gaussian screen-space quantities (differentiable) + integer binning data.
+    extra: optional dict of zero leaves {"ndc": (P,2), "rgb": (P,3), "cov6": (P,6)} added to the 2D mean (in NDC), the
+    final colour and the covariance entries."""
     dt = means3D.dtype
+    extra = extra or {}
     P = means3D.shape[0]
     focal_y = H / (2.0 * tanfovy)
     focal_x = W / (2.0 * tanfovx)
@@ -57,14 +94,19 @@ def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatri
     p_proj = p_hom[:, :3] * p_w
     in_front = p_view[:, 2] > 0.2
 
-    r, x, y, z = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
-    # standard rotation matrix of the (un-normalised) quaternion; glm fills COLUMNS with these triples, i.e. the
-    # glm matrix is this one transposed (CR/forward.cu:286-290)
-    Rstd = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(P, 3, 3)
-    S = torch.diag_embed(scale_modifier * scales)
-    Sigma = Rstd @ S @ S @ Rstd.transpose(1, 2)  # = M^T M with M = S R_glm
+    if cov3D_precomp is not None:
+        Sigma = cov6_to_mat(cov3D_precomp)                       # CR/forward.cu:484-493: used as given
+    else:
+        r, x, y, z = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
+        # standard rotation matrix of the (un-normalised) quaternion; glm fills COLUMNS with these triples, i.e. the
+        # glm matrix is this one transposed (CR/forward.cu:286-290)
+        Rstd = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(P, 3, 3)
+        S = torch.diag_embed(scale_modifier * scales)
+        Sigma = Rstd @ S @ S @ Rstd.transpose(1, 2)  # = M^T M with M = S R_glm
+    if "cov6" in extra:
+        Sigma = Sigma + cov6_to_mat(extra["cov6"])   # off-diagonal leaves feed both symmetric entries (CR/backward.cu:426-431)
 
     t = p_view
     limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
@@ -86,12 +128,15 @@ def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatri
     coef = torch.where((det0 <= 1e-6) | (det1 <= 1e-6), torch.zeros_like(coef), coef)
 
     # ray-space plane / normal (CR/forward.cu:135-260)
-    evals, evecs = torch.linalg.eigh(Sigma)
-    well = evals[:, 0] > 0.00000001
-    inv_w = evecs @ torch.diag_embed(1.0 / evals) @ evecs.transpose(1, 2)
-    emin = evecs[:, :, 0]
-    inv_i = emin[:, :, None] * emin[:, None, :]
-    Sinv = torch.where(well[:, None, None], inv_w, inv_i)
+    if sigma_inv is not None:
+        Sinv = _TruncatedInverse.apply(Sigma, sigma_inv)
+    else:
+        evals, evecs = torch.linalg.eigh(Sigma)
+        well = evals[:, 0] > 0.00000001
+        inv_w = evecs @ torch.diag_embed(1.0 / evals) @ evecs.transpose(1, 2)
+        emin = evecs[:, :, 0]
+        inv_i = emin[:, :, None] * emin[:, None, :]
+        Sinv = torch.where(well[:, None, None], inv_w, inv_i)
     Cinv = Rm @ Sinv @ Rm.t()
     uvh = torch.stack([txtz, tytz, torch.ones_like(txtz)], 1)
     m = (Cinv @ uvh[:, :, None])[:, :, 0]
@@ -126,7 +171,8 @@ def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatri
     mid = 0.5 * (a + c)
     lam = mid + torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
     radius = torch.ceil(3.0 * torch.sqrt(lam))
-    xy = torch.stack([((p_proj[:, 0].double() + 1.0) * W - 1.0) * 0.5, ((p_proj[:, 1].double() + 1.0) * H - 1.0) * 0.5], 1).to(dt)
+    ndc = p_proj[:, :2] + extra["ndc"] if "ndc" in extra else p_proj[:, :2]
+    xy = torch.stack([((ndc[:, 0].double() + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1].double() + 1.0) * H - 1.0) * 0.5], 1).to(dt)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     rad_i = radius.detach().to(torch.int64)
     xyd = xy.detach()
@@ -137,14 +183,19 @@ def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatri
     tiles = (rmaxx - rminx) * (rmaxy - rminy)
     visible = in_front & (det.detach() != 0) & (tiles > 0)
 
-    dirs = means3D - campos[None, :]
-    dirs = dirs / dirs.norm(dim=1, keepdim=True)
-    rgb = torch.clamp_min(eval_sh(sh_degree, shs, dirs), 0.0)
+    if colors_precomp is not None:
+        rgb = colors_precomp                                       # CR/forward.cu:528-533: no SH, no clamp
+    else:
+        dirs = means3D - campos[None, :]
+        dirs = dirs / dirs.norm(dim=1, keepdim=True)
+        rgb = torch.clamp_min(eval_sh(sh_degree, shs, dirs), 0.0)
+    if "rgb" in extra:
+        rgb = rgb + extra["rgb"]
     return dict(visible=visible, radii=torch.where(visible, rad_i, torch.zeros_like(rad_i)), xy=xy, conic=conic,
                 w=opacities.reshape(-1) * coef, rgb=rgb, ts=ts, ray_plane=ray_plane, normal=normal, cam_plane=cam_plane,
                 view_points=p_view, depth=p_view[:, 2].detach(), rect=(rminx, rminy, rmaxx, rmaxy),
                 tiles=torch.where(visible, tiles, torch.zeros_like(tiles)), gx=gx, gy=gy, focal_x=focal_x,
-                focal_y=focal_y)
+                focal_y=focal_y, Sigma=Sigma)
 
 
 def bin_tiles(pp):
@@ -170,8 +221,10 @@ def bin_tiles(pp):
     return ids, starts
 
 
-def render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset=None):
-    """Tile compositing (CR/forward.cu:672-821) with torch ops; returns the 8 images (variant planes zero)."""
+def render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset=None, keep_pairs=False):
+    """Tile compositing (CR/forward.cu:672-821) with torch ops; returns the 8 images (variant planes zero).
+    keep_pairs: retain, per tile, (Gaussian ids, G = exp(power) with its gradient kept, dx, dy) so that abs_grad_means2D()
+    can form the per-pair absolute sums of CR/backward.cu:1005-1006 after loss.backward()."""
     dt = pp["xy"].dtype
     geo = require_coord or require_depth
     gx, gy = pp["gx"], pp["gy"]
@@ -182,6 +235,7 @@ def render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset=
     pieces = {k: [] for k in out}
     where = []
     npairs = 0
+    kept = []
     for tidx in tiles:
         s, e = int(starts[tidx]), int(starts[tidx + 1])
         ty_, tx_ = divmod(tidx, gx)
@@ -197,7 +251,12 @@ def render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset=
         dy = pp["xy"][g, 1:2] - py
         con = pp["conic"][g]
         power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
-        alpha = torch.clamp(pp["w"][g][:, None] * torch.exp(power), max=0.99)
+        G = torch.exp(power)
+        if keep_pairs:
+            G.retain_grad()
+            kept.append((g, G, dx.detach(), dy.detach(), con.detach()))
+        araw = pp["w"][g][:, None] * G
+        alpha = araw + (torch.clamp(araw, max=0.99) - araw).detach()      # min(0.99, .), straight-through (see header)
         live = (power <= 0) & (alpha >= 1.0 / 255.0)
         a_eff = torch.where(live, alpha, torch.zeros_like(alpha))
         Tcum = torch.cumprod(1 - a_eff, 0)  # T after each entry (if it were blended)
@@ -248,15 +307,34 @@ def render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset=
                 C = out[k].shape[0]
                 out[k] = torch.index_copy(out[k].reshape(C, -1), 1, idx, torch.cat(pieces[k], 1)).reshape(C, H, W)
     out["npairs"] = npairs
+    if keep_pairs:
+        out["pairs"] = kept
     return out
 
 
+def abs_grad_means2D(pairs, P, W, H):
+    """dL_dmeans2D[:, 2] (CR/backward.cu:1005-1006): sum over a Gaussian's pairs of |dL/dG dG/ddx W/2| + |dL/dG dG/ddy H/2|
+    (the G-only part of the mean gradient).  Call after loss.backward(); `pairs` = render(..., keep_pairs=True)["pairs"]."""
+    z = torch.zeros(P, dtype=pairs[0][1].dtype if pairs else torch.float64)
+    for g, G, dx, dy, con in pairs:
+        if G.grad is None:
+            continue
+        gdx, gdy = G.detach() * dx, G.detach() * dy
+        dGdx = -gdx * con[:, 0:1] - gdy * con[:, 1:2]
+        dGdy = -gdy * con[:, 2:3] - gdx * con[:, 1:2]
+        z.index_add_(0, g, ((G.grad * dGdx * (0.5 * W)).abs() + (G.grad * dGdy * (0.5 * H)).abs()).sum(1))
+    return z
+
+
 def rasterize(bg, means3D, opacities, scales, rotations, shs, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
-              kernel_size, H, W, sh_degree, require_coord, require_depth, scale_modifier=1.0, tile_subset=None):
+              kernel_size, H, W, sh_degree, require_coord, require_depth, scale_modifier=1.0, tile_subset=None,
+              sigma_inv=None, cov3D_precomp=None, colors_precomp=None, extra=None, keep_pairs=False):
     pp = preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,
-                    kernel_size, scale_modifier, sh_degree)
+                    kernel_size, scale_modifier, sh_degree, sigma_inv=sigma_inv, cov3D_precomp=cov3D_precomp,
+                    colors_precomp=colors_precomp, extra=extra)
     ids, starts = bin_tiles(pp)
-    out = render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset)
+    out = render(pp, ids, starts, bg, W, H, require_coord, require_depth, tile_subset, keep_pairs=keep_pairs)
+    out["pp"] = pp
     out["radii"] = pp["radii"]
     out["ids"] = ids
     out["starts"] = starts
