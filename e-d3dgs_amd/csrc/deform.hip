@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -2568,6 +2569,8 @@ struct HeadJob {
 constexpr int MAXHEADJOBS = 2 * NHEAD;
 struct HeadWgradArgs {
     int P, njobs;
+    unsigned long long *timing;   // diagnostic (ED3DGS_WG_TIMING): per-phase cycle sums of block 0's waves, [wave][8]
+    int ablate;   // diagnostic (ED3DGS_WG_ABLATE; results are then wrong): 1 no DMA after the first slab, 2 no dW2 MFMAs, 4 no split pass
     int blk_begin[MAXHEADJOBS + 1];
     HeadJob job[MAXHEADJOBS];
 };
@@ -3045,6 +3048,315 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     }
     if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Head weight gradients, exact three-piece mode, round-2 form ("tr": operands through the hardware's transposing LDS read).
+// What bounded deform_head_wgrad_narrow_bn_kernel was its own instruction stream: every wave gathered the `a` operand of
+// its 2 x 2 patch with eight 4-byte LDS reads per fragment and split it into bf16 pieces itself (two waves per value),
+// and formed two g_z tiles that its neighbour formed as well.  Here
+//   * the block splits the `a` slab ONCE into the three bf16 pieces, into an LDS image laid out for ds_read_b64_tr_b16:
+//     256-byte blocks [n-tile][piece][4 Gaussians][32 features], so a B fragment (8 Gaussians of one feature) is two
+//     conflict-free transposing reads and no VALU work;
+//   * wave w owns the m-tile w of dW2 (the features 32w.. of g_z) and all four n-tiles: one g_z tile per wave and slab,
+//     formed once, and the same 64 accumulator registers as a 2 x 2 patch;
+//   * the wide (48-output SH) head runs in the same form with dW2 and dW3 in three pieces on the bf16 MFMA (round 1 kept it
+//     on the f32-operand MFMA, 0.30 ms, for want of registers in the 2 x 2 form); g_y . W3 (K = 48) stays on the f32 MFMA
+//     with fp32 operands as they stand -- as long as the three-piece form plus its operand splitting, 12 registers fewer.
+// Slabs of relu(z) (fp32, double-buffered) and a (fp32, one staging buffer) come in by LDS-DMA; g_y goes through registers.
+// Two barriers per slab: [DMA landed] store g_y, split pass [image ready]; the next slab's DMA is issued after the second.
+// LDS: SEPARATE objects, not one carved array, and the slab loop unrolled by two so that every access names its object:
+// after an LDS-DMA the compiler makes every LDS read it cannot prove disjoint from the DMA's destination wait for
+// vmcnt(0); with one `extern __shared__` array that put the wait for the NEXT slab's DMA in front of this slab's first
+// transposing read (and, with one z array, in front of the first read of relu(z)), i.e. HBM latency in series with the MFMAs.
+// 80 KB (wide) / 74 KB (narrow): two blocks per CU, one block's non-MFMA phases run under the other's MFMAs.
+// ------------------------------------------------------------------------------------------------------------
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_read2(const char *img, int off0, int off1)
+{
+    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4 *)(img + off0));
+    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4 *)(img + off1));
+    const i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// byte offset, in the piece image, of the 8-byte chunk (Gaussian g of the slab, features 4 cc .. 4 cc + 3), piece q.
+// A 256-byte block holds 4 Gaussians x 32 features of one (n-tile, piece); the row rotation by the n-tile spreads the split
+// pass's writes over the banks and leaves a block a bijection onto the 64 banks for the reads.
+__device__ __forceinline__ int trimg_off(int g, int cc, int q)
+{
+    const int nt = cc >> 3;
+    return (((nt * 3 + q) * 8 + (g >> 2)) << 8) + ((((g & 3) + nt) & 3) << 6) + ((cc & 7) << 3);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_tr_kernel(HeadWgradArgs a)
+{
+    constexpr int SLAB = 32 * HJ_W;                  // floats per fp32 slab
+    constexpr int LDG = WIDE ? 49 : 5;               // g_y slab row stride (odd); the last column stays zero
+    constexpr int NG = WIDE ? 6 : 1;                 // g_y elements staged per thread and slab
+    constexpr int KW3 = WIDE ? 24 : 2;               // k-steps of g_y . W3 on the f32 32x32x2 MFMA (two head outputs per step)
+    __shared__ float zbuf0[SLAB];
+    __shared__ float zbuf1[SLAB];
+    __shared__ float astage[SLAB];
+    __shared__ __attribute__((aligned(256))) char aimg[24576];   // piece image of the a slab
+    __shared__ float gs[32 * LDG];
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    const HeadJob &J = a.job[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = J.nk, P = a.P;
+    const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int p0 = split * chunk, p1 = min(P, p0 + chunk);
+    if (p0 >= p1) return;
+    const int nslab = (p1 - p0 + 31) / 32;
+    for (int e = tid; e < 32 * LDG; e += 256) gs[e] = 0.f;
+
+    // W3 of this wave's feature tile as the B operand of the f32 32x32x2 product: lane (feature c, k-slot h) holds W3[2 kk + h][feature]
+    float w3f[KW3];
+#pragma unroll
+    for (int kk = 0; kk < KW3; kk++) {
+        const int k = 2 * kk + h;
+        w3f[kk] = (k < nk) ? J.W3[(size_t)k * HJ_W + wave * 32 + c] : 0.f;
+    }
+    f32x16 acc[4], acc3[WIDE ? 2 : 1];
+    f32x4 acc3n[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        acc[0][r] = acc[1][r] = acc[2][r] = acc[3][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < (WIDE ? 2 : 1); t++) acc3[t][r] = 0.f;
+    }
+    float bsum2 = 0.f;
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 gv, g2v;
+    const bool has_g2 = J.G2 != nullptr;
+    const int gcount = 32 * nk;
+    // db3 = sum over Gaussians of g_y: every thread sums the slab elements it stages (element e of a slab is head output
+    // e % nk in EVERY slab, since a slab holds 32 * nk elements) and adds its NG partial sums once, at the end
+    float bsum3[NG];
+#pragma unroll
+    for (int i = 0; i < NG; i++) bsum3[i] = 0.f;
+    // ... and (row e / nk, column e % nk) likewise: LDS offsets computed once, two per register (a division by the runtime
+    // nk is ~40 instructions)
+    unsigned gpk[(NG + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        const int e = tid + 256 * i, r = min(e / nk, 31), cc = e - (e / nk) * nk;
+        const unsigned v = (unsigned)(r * LDG + cc) | ((unsigned)r << 11);          // offset < 2048, row in the high bits
+        if (i & 1) gpk[i >> 1] |= v << 16; else gpk[i >> 1] = v;
+    }
+
+    // 16 KB = 16 DMA instructions of 1 KB (2 rows), 4 per wave; rows past the range re-read the last row
+    auto dma_slab = [&](const float *src, float *dst, int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int piece = i * 4 + wave, row = piece * 2 + h, col = c * 4;
+            const size_t o = (size_t)min(r0 + row, p1 - 1) * HJ_W + col;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
+        }
+    };
+    auto load_g = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int e = tid + 256 * i;
+            const size_t o = (size_t)r0 * nk + min(e, (p1 - r0) * nk - 1);
+            gv[i] = J.G[o];
+            if (has_g2) g2v[i] = J.G2[o];
+        }
+    };
+    auto store_g = [&](int slab) {
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int e = tid + 256 * i;
+            if (e < gcount) {
+                const unsigned pk = (gpk[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const int r = (int)(pk >> 11), off = (int)(pk & 0x7FFu);
+                float v = gv[i];
+                if (has_g2) v += g2v[i];
+                v = (r0 + r < p1) ? v * J.gscale : 0.f;                  // rows past the range contribute nothing
+                gs[off] = v;
+                bsum3[i] += v;
+            }
+        }
+    };
+    // this lane's part of a transposing read: the group's row (lane & 15) >> 2, chunk lane & 3 of feature half (lane >> 4) & 1.
+    // Per n-tile u one lane-dependent base (the row rotation depends on u); k-step, quad and piece are immediates:
+    // trimg_off(16 st + 4 h + row + 8 rd, 8 u + cc, q) = trb[u] + (3 u + q) * 2048 + (4 st + 2 rd) * 256
+    const int tr_row = (lane & 15) >> 2, tr_cc = ((lane >> 4) & 1) * 4 + (lane & 3);
+    int trb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) trb[u] = (h << 8) + (((tr_row + u) & 3) << 6) + (tr_cc << 3);
+
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timed = a.timing != nullptr && blockIdx.x == 0;
+#define WG_MARK(i_) do { if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tph[i_] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    if (timed) tlast = clock64();
+    dma_slab(J.ZR, zbuf0, 0);
+    dma_slab(J.A, astage, 0);
+    load_g(0);
+    auto body = [&](auto bufc, int slab) {
+        constexpr int BUF = decltype(bufc)::value;
+        const float *zs = BUF ? zbuf1 : zbuf0;
+        __syncthreads();                                   // slab's DMA landed; every wave is done with the previous slab
+        WG_MARK(0);
+        store_g(slab);
+        // split pass: 1024 chunks of 4 features, 4 per thread; x = p0 + p1 + p2 exactly (see split8_n)
+        if (!(a.ablate & 4))
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + 256 * i, g = idx >> 5, cc = idx & 31;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(astage + g * HJ_W + cc * 4);
+            float r1[4], r2[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                r1[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xFFFF0000u);
+                r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xFFFF0000u);
+            }
+            uint2 w0 = make_uint2(pack_hi16(v[0], v[1]), pack_hi16(v[2], v[3]));
+            uint2 w1 = make_uint2(pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3]));
+            uint2 w2 = make_uint2(pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3]));
+            *reinterpret_cast<uint2 *>(aimg + trimg_off(g, cc, 0)) = w0;
+            *reinterpret_cast<uint2 *>(aimg + trimg_off(g, cc, 1)) = w1;
+            *reinterpret_cast<uint2 *>(aimg + trimg_off(g, cc, 2)) = w2;
+        }
+        WG_MARK(1);
+        __syncthreads();                                   // image and g_y slab ready; the staging buffer is free again
+        WG_MARK(2);
+        if (slab + 1 < nslab && !(a.ablate & 1)) { dma_slab(J.ZR, BUF ? zbuf0 : zbuf1, slab + 1); dma_slab(J.A, astage, slab + 1); load_g(slab + 1); }
+        WG_MARK(3);
+
+        // g_z tile of this wave (Gaussian on the register index), masked by relu(z) > 0
+        f32x16 dd = zero_acc();
+        if constexpr (WIDE) {
+            // operands of 8 k-steps are read from LDS together, then the 8 (dependent) MFMAs run back to back
+#pragma unroll
+            for (int k0 = 0; k0 < KW3; k0 += 8) {
+                float ga8[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) ga8[q] = gs[c * LDG + 2 * (k0 + q) + h];
+#pragma unroll
+                for (int q = 0; q < 8; q++) dd = __builtin_amdgcn_mfma_f32_32x32x2f32(ga8[q], w3f[k0 + q], dd, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KW3; kk++) dd = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], w3f[kk], dd, 0, 0, 0);
+        }
+        XSplitN<3> gzs;
+        {
+            float gz[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                gz[r] = zs[row * HJ_W + wave * 32 + c] > 0.f ? dd[r] : 0.f;
+                bsum2 += gz[r];
+            }
+            split_tile_n<3>(gz, gzs);
+        }
+        WG_MARK(4);
+        // dW2 row block: A = g_z (registers 8 s .. 8 s + 7 are k-step s: Gaussians 16 s + 8 (j >> 2) + 4 h + (j & 3)),
+        // B = the a pieces of those Gaussians: quads 4 s + h and 4 s + 2 + h of the image
+        if (!(a.ablate & 2))
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            bf16x8 ga[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) ga[q] = gzs.p[q][st];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                bf16x8 bp[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) bp[q] = tr_read2(aimg + trb[u], (3 * u + q) * 2048 + (4 * st) * 256, (3 * u + q) * 2048 + (4 * st + 2) * 256);
+                acc[u] = mfma_bn<3>(ga, bp, acc[u]);
+            }
+        }
+        WG_MARK(5);
+        if constexpr (WIDE) {
+            // dW3 = g_y^T relu(z): A = g_y columns, B = relu(z) columns of this wave's feature tile, gathered over the k-step's rows
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v8[j] = zs[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * HJ_W + wave * 32 + c];
+                bf16x8 zp[3];
+                split8_n<3>(v8, zp);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int col = min(32 * t + c, LDG - 1);      // head outputs past 47: the zero column
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v8[j] = gs[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * LDG + col];
+                    bf16x8 gp[3];
+                    split8_n<3>(v8, gp);
+                    acc3[t] = mfma_bn<3>(gp, zp, acc3[t]);
+                }
+            }
+        } else {
+            // operands of eight k-slots are fetched together and four accumulation chains run interleaved: the plain loop
+            // compiles to read / wait / MFMA per slot -- sixteen LDS latencies and sixteen dependent 4x4x1 MFMAs in a row
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 8) {
+                float ga8[8], zb8[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int row = 2 * (k0 + q) + h;
+                    ga8[q] = gs[row * LDG + (lane & 3)];
+                    zb8[q] = zs[row * HJ_W + wave * 32 + c];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc3n[q & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(ga8[q], zb8[q], acc3n[q & 3], 0, 0, 0);
+            }
+        }
+        WG_MARK(6);
+    };
+    for (int slab = 0; slab < nslab; slab += 2) {
+        body(std::integral_constant<int, 0>(), slab);
+        if (slab + 1 < nslab) body(std::integral_constant<int, 1>(), slab + 1);
+    }
+    if (timed && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a.timing[wave * 8 + i] = i < 7 ? tph[i] : (unsigned long long)nslab;
+    }
+#undef WG_MARK
+    // flush: dW2[m = 32 w + row][n = 32 u + column]
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mi = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            atomicAdd(J.dW2 + (size_t)mi * HJ_W + u * 32 + c, acc[u][r]);
+        }
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, acc3[t][r]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float vs = (acc3n[0][i] + acc3n[1][i]) + (acc3n[2][i] + acc3n[3][i]);
+            const float v = vs + __shfl_xor(vs, 32);
+            if (h == 0 && i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, v);
+        }
+    }
+    {
+        const float v = bsum2 + __shfl_xor(bsum2, 32);
+        if (h == 0) atomicAdd(J.db2 + wave * 32 + c, v);
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        const int e = tid + 256 * i;
+        if (e < gcount) atomicAdd(J.db3 + e % nk, bsum3[i]);
+    }
 }
 
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
@@ -3758,7 +4070,25 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const bool b3 = use_b3(cfg);
         const int sub = wide ? ED3DGS_PROF_DEFORM_WGRAD_WIDE : ED3DGS_PROF_DEFORM_WGRAD_NARROW;
         const bool ps = prof_start(sub, s);
-        if (wide) {
+        const bool tr_form = fwd_pieces(cfg) == 3 && !getenv("ED3DGS_DEFORM_WGRAD_R1");   // round-2 kernels (exact three-piece mode)
+        if (tr_form) {
+            static unsigned long long *wg_timing = nullptr;
+            if (getenv("ED3DGS_WG_TIMING") && !wg_timing) (void)hipMalloc((void **)&wg_timing, 2 * 32 * sizeof(unsigned long long));
+            ha.timing = getenv("ED3DGS_WG_TIMING") ? wg_timing + 32 * wide : nullptr;
+            ha.ablate = getenv("ED3DGS_WG_ABLATE") ? atoi(getenv("ED3DGS_WG_ABLATE")) : 0;
+            if (wide) hipLaunchKernelGGL(deform_head_wgrad_tr_kernel<true>, dim3(nblk), dim3(256), 0, s, ha);   // static LDS: 80 KB / 74 KB
+            else hipLaunchKernelGGL(deform_head_wgrad_tr_kernel<false>, dim3(nblk), dim3(256), 0, s, ha);
+            if (ha.timing) {   // diagnostic: phase cycle sums of block 0 (0 S1 wait, 1 store_g + split, 2 S2 wait, 3 DMA issue, 4 g_z, 5 dW2, 6 dW3)
+                unsigned long long t[32];
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(t, ha.timing, sizeof t, hipMemcpyDeviceToHost);
+                for (int wv = 0; wv < 4; wv++) {
+                    fprintf(stderr, "[ed3dgs] wgrad_tr<%d> wave %d, %llu slabs, cycles/slab:", wide, wv, t[wv * 8 + 7]);
+                    for (int i = 0; i < 7; i++) fprintf(stderr, " %llu", t[wv * 8 + i] / (t[wv * 8 + 7] ? t[wv * 8 + 7] : 1));
+                    fprintf(stderr, "\n");
+                }
+            }
+        } else if (wide) {
             const void *fn = b3 ? (const void *)deform_head_wgrad_kernel<true, true, false> : (const void *)deform_head_wgrad_kernel<true, false>;
             if (!check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size")) return ED3DGS_ERR_HIP;
             if (b3) {   // split-bf16: dW2/db2 here, dW3/db3 in their own launch (register budget)
