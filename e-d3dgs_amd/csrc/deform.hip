@@ -3352,11 +3352,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float v = bsum2 + __shfl_xor(bsum2, 32);
         if (h == 0) atomicAdd(J.db2 + wave * 32 + c, v);
     }
+    // db3: the threads' partial sums meet in LDS first (one global atomic per head output and block; 32 threads hold each output)
+    __syncthreads();
+    if (tid < 64) gs[tid] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NG; i++) {
         const int e = tid + 256 * i;
-        if (e < gcount) atomicAdd(J.db3 + e % nk, bsum3[i]);
+        if (e < gcount) {
+            const unsigned pk = (gpk[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            atomicAdd(&gs[(int)(pk & 0x7FFu) - (int)(pk >> 11) * LDG], bsum3[i]);
+        }
     }
+    __syncthreads();
+    if (tid < nk) atomicAdd(J.db3 + tid, gs[tid]);
 }
 
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
