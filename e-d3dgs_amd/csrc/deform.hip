@@ -103,6 +103,7 @@ struct DeformDev {
     int keep;      // forward writes a = relu(hid) and relu(z_k) for the backward (activations kept instead of re-formed)
     int store_gz;  // dgrad writes g_z (only the generic wgrad path reads it back)
     int ablate;  // diagnostic builds only: bit mask of phases to skip (timing experiments; results are then wrong)
+    unsigned long long *timing;  // diagnostic (ED3DGS_FWD_TIMING): per-phase cycle sums of block 0's waves in the narrow-head tile loop
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1227,6 +1228,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (has_tail) { int e = b % n_en; for (int k = 0; k < NHEAD; k++) if (d.enabled[k] && e-- == 0) tail_k = k; }
     const int tail_bi = d.full_rounds * G + (n_en ? b / n_en : 0);
     (void)n_bi;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, ntile = 0;
+    const bool timed = d.timing != nullptr && blockIdx.x == 0;
+#define FW_MARK(i_) do { if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tph[i_] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
     ED3_GPIPE(NT, TS)
     GPIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
     for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
@@ -1289,12 +1293,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         f32x4 yn = {0.f, 0.f, 0.f, 0.f}, yn2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
                         for (int nt = 0; nt < NT; nt++) {
+                            if (timed) { tlast = clock64(); ntile++; }
                             const float *wb = PIPE_CUR();
                             f32x4 bv[4];
                             load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
                             f32x16 acc = zero_acc();
 #pragma unroll
                             for (int kt = 0; kt < NT; kt++) acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
+                            FW_MARK(0);
+                            if (timed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                            FW_MARK(1);
                             // the 16 W3 values of this lane are fetched from LDS in one go, ahead of the epilogue's VALU
                             // work: read-wait-MFMA per k-slot (what the compiler emits for the plain loop) is a chain of
                             // 16 LDS latencies, as long as the tile's 64 big MFMAs
@@ -1309,12 +1317,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
                             if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
                             __builtin_amdgcn_sched_barrier(0);
+                            FW_MARK(2);
                             // two interleaved accumulation chains: a dependent 4x4x1 MFMA waits out the previous one's passes
 #pragma unroll
                             for (int kk = 0; kk < 16; kk += 2) {
                                 yn = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk], z[0][kk], yn, 0, 0, 0);
                                 yn2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk + 1], z[0][kk + 1], yn2, 0, 0, 0);
                             }
+                            FW_MARK(3);
+                            if (timed) { __syncthreads(); FW_MARK(4); if (pipe_n + 2 < pipe_total) GPIPE_ISSUE(pipe_n & 1); pipe_n++; FW_MARK(5); }
+                            else
                             GPIPE_ADVANCE();
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
@@ -1371,6 +1383,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int r = 0; r < 8; r++) csh[16 + r] += y[1][r] * hc;
                     }
                 }
+            }
+            if (timed && s == 1 && lane == 0 && it == my_full - 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) d.timing[wave * 8 + i] = i < 7 ? tph[i] : ntile;
             }
             float *const *dst = (s == 0) ? d.sub : d.out;
             if (gvalid && dst[0]) {   // a tail unit owns one head's tensors (a disabled head's pass-through goes with head 0)
@@ -3818,6 +3834,9 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     fill_dev(cfg, d, false);
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.keep = keep ? 1 : 0;
+    static unsigned long long *fwd_timing = nullptr;
+    if (getenv("ED3DGS_FWD_TIMING") && !fwd_timing) (void)hipMalloc((void **)&fwd_timing, 32 * sizeof(unsigned long long));
+    d.timing = getenv("ED3DGS_FWD_TIMING") ? fwd_timing : nullptr;
     if (keep) for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.MK[st] = w.MK[st]; }
     d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh;
     float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
@@ -3853,6 +3872,16 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         hipLaunchKernelGGL((deform_forward_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
     });
     if (pf) prof_stop(ED3DGS_PROF_DEFORM_FORWARD, s);
+    if (d.timing) {   // diagnostic: narrow-head tile loop of block 0 (0 weights + MFMAs, 1 vmcnt wait, 2 epilogue + kept stores, 3 output MFMAs, 4 barrier, 5 DMA issue)
+        unsigned long long t[32];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(t, d.timing, sizeof t, hipMemcpyDeviceToHost);
+        for (int wv = 0; wv < 4; wv++) {
+            fprintf(stderr, "[ed3dgs] fwdtile keep=%d wave %d, %llu tiles, cycles/tile:", d.keep, wv, t[wv * 8 + 7]);
+            for (int i = 0; i < 7; i++) fprintf(stderr, " %llu", t[wv * 8 + i] / (t[wv * 8 + 7] ? t[wv * 8 + 7] : 1));
+            fprintf(stderr, "\n");
+        }
+    }
     if (!check_hip(hipGetLastError(), "deform forward")) return ED3DGS_ERR_HIP;
     return keep ? 1 : 0;
 }
