@@ -70,8 +70,11 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     F = wl["frames"]
     inflight = []
     ups = [grads["color"], grads["depth"], grads["mdepth"], grads["normal"]]
-    ups_color_flat = grads["color"].reshape(-1)
-    one = torch.ones((), device=device)
+    ups_color_flat = grads["color"].reshape(-1).contiguous()
+    from ed3dgs_amd import _lib
+    L = _lib.lib()
+    stats_acc = torch.zeros(4, device=device)
+    stats_out = [torch.zeros(3, device=device), torch.zeros(3, device=device)]
 
     def step(item, backward=True, coord=False):
         ci, fi = D.item_of(item, wl["cams"], F)
@@ -84,11 +87,17 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
         # path): they enter the backward directly
         outs = [pkg["render"], pkg["expected_depth"], pkg["median_depth"], pkg["normal"]]
         torch.autograd.backward(outs, ups)
-        with torch.no_grad():
-            # logging stand-in (train.py logs the image loss and PSNR): <image, its upstream gradient> and a PSNR
-            loss = torch.vdot(pkg["render"].reshape(-1), ups_color_flat)
-            mse = (pkg["render"] - 0.5).square().mean()
-            stats = torch.stack([loss, -10.0 * torch.log10(mse), one])
+        # logging stand-in (train.py logs the image loss and PSNR): <image, its upstream gradient> and a PSNR against mid-grey,
+        # one fused launch (csrc/stats.hip; ten torch launches, 90 us, as separate ops) into one of two alternating buffers
+        # (the previous step's vector may still be in its all-reduce)
+        stats = stats_out[step.n & 1]
+        step.n += 1
+        img = pkg["render"].detach()
+        rc = L.ed3dgs_image_stats(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(ups_color_flat.data_ptr()),
+                                  ctypes.c_size_t(img.numel()), ctypes.c_float(0.5), ctypes.c_void_p(stats_acc.data_ptr()),
+                                  ctypes.c_void_p(stats.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc < 0:
+            raise RuntimeError(_lib.last_error())
         # the path's one collective (RCCL over xGMI): 12 bytes, waited for one step later (the stream, not the host,
         # waits), so that ranks are not re-synchronised every step
         if inflight:
@@ -106,6 +115,7 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
             inflight.pop().wait()
 
     step.drain = drain
+    step.n = 0
     return step
 
 

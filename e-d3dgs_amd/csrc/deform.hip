@@ -175,9 +175,9 @@ __device__ inline float frame_time(const FrameArgs &a)
     return a.time + off;
 }
 
-__global__ void __launch_bounds__(256) deform_frame_kernel(FrameArgs a)
+__device__ __forceinline__ void deform_frame_kernel_body(const FrameArgs &a, const int bx, const int by, const int nbx)
 {
-    const int s = blockIdx.x;
+    const int s = bx;
     if (!a.use_stage[s]) return;
     __shared__ float sh_h[512];
     float *fs = a.fs + (size_t)s * FS_STRIDE;
@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256) deform_frame_kernel(FrameArgs a)
         a.hb[s][o] = acc;
     }
 }
+__global__ void __launch_bounds__(256) deform_frame_kernel(FrameArgs a) { deform_frame_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------------------
 // fragment builder: one thread per fragment element
@@ -231,11 +232,11 @@ struct FragArgs {
     FragLayout fl;
 };
 
-__global__ void __launch_bounds__(256) deform_frag_kernel(FragArgs a)
+__device__ __forceinline__ void deform_frag_kernel_body(const FragArgs &a, const int bx, const int by, const int nbx)
 {
-    const int s = blockIdx.y;
+    const int s = by;
     if (!a.use_stage[s]) return;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)bx * blockDim.x + threadIdx.x;
     const float *p = a.params[s];
     float *f = a.frag[s];
     const int W = a.W, NT = a.NT, ET = a.ET, ld1 = a.TD + a.E;
@@ -286,13 +287,14 @@ __global__ void __launch_bounds__(256) deform_frag_kernel(FragArgs a)
         f[a.fl.B3 + i] = o < head_nk(k, a.n_sh) ? p[a.pl.b3[k] + o] : 0.f;
     }
 }
+__global__ void __launch_bounds__(256) deform_frag_kernel(FragArgs a) { deform_frag_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // chunk builder for the LDS-pipelined kernels: one thread per chunk element (see frag_layout)
-__global__ void __launch_bounds__(256) deform_chunk_kernel(FragArgs a)
+__device__ __forceinline__ void deform_chunk_kernel_body(const FragArgs &a, const int bx, const int by, const int nbx)
 {
-    const int s = blockIdx.y;
+    const int s = by;
     if (!a.use_stage[s]) return;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)bx * blockDim.x + threadIdx.x;
     const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
     const int CHF = a.fl.ch_floats;
     if (idx >= (size_t)a.fl.n_chunks * CHF) return;
@@ -323,6 +325,7 @@ __global__ void __launch_bounds__(256) deform_chunk_kernel(FragArgs a)
     }
     a.frag[s][a.fl.CH + idx] = v;
 }
+__global__ void __launch_bounds__(256) deform_chunk_kernel(FragArgs a) { deform_chunk_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // Split-bf16 ("b3") fragments for the forward's v_mfma_f32_32x32x16_bf16 path: a 32 (out) x 32 (k) weight tile keeps its
 // 4 KB, as [k-step s = 0,1][part = hi,lo][lane][8 bf16]; element j of lane (r = lane & 31, h = lane >> 5) is
@@ -335,13 +338,13 @@ __device__ __forceinline__ uint32_t bf16_rne(float x)
     const uint32_t u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-template <int NP>   // pieces per value: 2 (hi, lo) or 3 (x = p0 + p1 + p2 exactly: 3 x 8 significant bits)
-__global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a)
+template <int NP>
+__device__ __forceinline__ void deform_chunk_b3_kernel_body(const FragArgs &a, const int bx, const int by, const int nbx)
 {
-    const int s = blockIdx.y;
+    const int s = by;
     if (!a.use_stage[s]) return;
     constexpr int TS = NP * 512;   // floats per tile: [k-step 2][piece NP][lane 64][8 bf16]
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)bx * blockDim.x + threadIdx.x;
     const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
     const int CHF = ((NT + OTMAX) * TS + 1023) & ~1023;   // chunk stride (ChunkSeq)
     if (idx >= (size_t)a.fl.n_chunks * CHF) return;
@@ -383,15 +386,17 @@ __global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a)
     }
     a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
 }
+template <int NP>
+__global__ void __launch_bounds__(256) deform_chunk_b3_kernel(FragArgs a) { deform_chunk_b3_kernel_body<NP>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // backward chunk layout (frag_layout, bwd) with the transposed tiles the kept-activation data gradient reads in the b3
 // format: F3T (rgb head only; narrow heads keep the fp32 fragment), F2T, and the transposed trunk F1T.  The forward F2
 // tiles at the head of each chunk are not read by that kernel and are left untouched.
-__global__ void __launch_bounds__(256) deform_chunk_b3_bwd_kernel(FragArgs a)
+__device__ __forceinline__ void deform_chunk_b3_bwd_kernel_body(const FragArgs &a, const int bx, const int by, const int nbx)
 {
-    const int s = blockIdx.y;
+    const int s = by;
     if (!a.use_stage[s]) return;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)bx * blockDim.x + threadIdx.x;
     const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
     const int CHF = a.fl.ch_floats;
     if (idx >= (size_t)a.fl.n_chunks * CHF) return;
@@ -429,17 +434,18 @@ __global__ void __launch_bounds__(256) deform_chunk_b3_bwd_kernel(FragArgs a)
     }
     a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
 }
+__global__ void __launch_bounds__(256) deform_chunk_b3_bwd_kernel(FragArgs a) { deform_chunk_b3_bwd_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // chunks of the kept-activation data gradient in the N-piece format, compact: chunk (k, nt) = [F3T (OTMAX tiles) | F2T (NT
 // tiles)], last chunk = F1T (NT tiles); tiles of NP * 512 floats as in deform_chunk_b3_kernel; narrow heads' F3T in the
 // fp32 fragment layout.
 template <int NP>
-__global__ void __launch_bounds__(256) deform_chunk_kept_kernel(FragArgs a)
+__device__ __forceinline__ void deform_chunk_kept_kernel_body(const FragArgs &a, const int bx, const int by, const int nbx)
 {
-    const int s = blockIdx.y;
+    const int s = by;
     if (!a.use_stage[s]) return;
     constexpr int TS = NP * 512;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)bx * blockDim.x + threadIdx.x;
     const int NT = a.NT, W = a.W, ld1 = a.TD + a.E;
     const int CHK = ((NT + OTMAX) * TS + 1023) & ~1023, NCH = NHEAD * NT + 1;
     if (idx >= (size_t)NCH * CHK) return;
@@ -447,10 +453,12 @@ __global__ void __launch_bounds__(256) deform_chunk_kept_kernel(FragArgs a)
     const int t = o / TS, f = o % TS;
     const float *p = a.params[s];
     const bool last = cidx == NCH - 1;
-    if (t >= NT + OTMAX || (last && t >= NT)) return;
+    // (slots no chunk element lives in are zeroed: this kernel owns the whole chunk region -- round 1 ran it AFTER the fp32
+    // chunk builder, whose leftovers filled them; as parts of one launch the two would race, so the fp32 builder is skipped)
+    if (t >= NT + OTMAX || (last && t >= NT)) { a.frag[s][a.fl.CH + idx] = 0.f; return; }
     const int k = cidx / NT, nt = cidx % NT;
     if (!last && t < OTMAX && k < 4) {   // narrow head: F3T in the fp32 fragment layout
-        if (f >= 1024) return;
+        if (f >= 1024) { a.frag[s][a.fl.CH + idx] = 0.f; return; }
         const int lane = f & 63, kk = (f >> 6) & 15, fs = fslot(kk, lane >> 5), cl = lane & 31;
         const int row = t * 32 + fs;
         a.frag[s][a.fl.CH + idx] = row < head_nk(k, a.n_sh) ? p[a.pl.W3[k] + (size_t)row * W + nt * 32 + cl] : 0.f;
@@ -482,6 +490,8 @@ __global__ void __launch_bounds__(256) deform_chunk_kept_kernel(FragArgs a)
     }
     a.frag[s][a.fl.CH + idx] = __uint_as_float(packed);
 }
+template <int NP>
+__global__ void __launch_bounds__(256) deform_chunk_kept_kernel(FragArgs a) { deform_chunk_kept_kernel_body<NP>(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------------------
 // MFMA helpers
@@ -3583,13 +3593,46 @@ struct ZeroArgs {
     float *p[4];
     size_t n[4];
 };
-__global__ void __launch_bounds__(256) deform_zero_kernel(ZeroArgs a)
+__device__ __forceinline__ void deform_zero_kernel_body(const ZeroArgs &a, const int bx, const int by, const int nbx)
 {
     for (int q = 0; q < 4; q++)
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[q]; i += (size_t)gridDim.x * blockDim.x) a.p[q][i] = 0.f;
+        for (size_t i = (size_t)bx * blockDim.x + threadIdx.x; i < a.n[q]; i += (size_t)nbx * blockDim.x) a.p[q][i] = 0.f;
 }
+__global__ void __launch_bounds__(256) deform_zero_kernel(ZeroArgs a) { deform_zero_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
 
 // frame backward: dW1[:, :TD] = g_hb (x) h ; g_h = W1[:, :TD]^T g_hb ; table / offsets gradients
+// One launch for everything a call prepares before its big kernels (round 1: three launches in the forward, five and a memset in
+// the backward, ~5 us each and all independent of one another): the weight re-layouts (fragments, LDS chunks, kept-gradient
+// chunks), the per-frame state, and -- backward -- the zeroing of the accumulated outputs.  Block ranges select the part.
+struct PrepArgs {
+    FragArgs fa;
+    FrameArgs fr;
+    ZeroArgs za;
+    int nb[6];          // blocks of: fragments, chunks, b3 backward chunks, kept chunks, frame (2), zeroing
+    int chunk_pieces;   // 3 / 2: deform_chunk_b3_kernel<3 / 2>; 0: deform_chunk_kernel
+};
+__global__ void __launch_bounds__(256) deform_prep_kernel(PrepArgs p)
+{
+    int bx = blockIdx.x;
+    const int by = blockIdx.y;
+    if (bx < p.nb[0]) { deform_frag_kernel_body(p.fa, bx, by, p.nb[0]); return; }
+    bx -= p.nb[0];
+    if (bx < p.nb[1]) {
+        if (p.chunk_pieces == 3) deform_chunk_b3_kernel_body<3>(p.fa, bx, by, p.nb[1]);
+        else if (p.chunk_pieces == 2) deform_chunk_b3_kernel_body<2>(p.fa, bx, by, p.nb[1]);
+        else deform_chunk_kernel_body(p.fa, bx, by, p.nb[1]);
+        return;
+    }
+    bx -= p.nb[1];
+    if (bx < p.nb[2]) { deform_chunk_b3_bwd_kernel_body(p.fa, bx, by, p.nb[2]); return; }
+    bx -= p.nb[2];
+    if (bx < p.nb[3]) { deform_chunk_kept_kernel_body<3>(p.fa, bx, by, p.nb[3]); return; }
+    bx -= p.nb[3];
+    if (bx < p.nb[4]) { if (by == 0) deform_frame_kernel_body(p.fr, bx, 0, p.nb[4]); return; }
+    bx -= p.nb[4];
+    if (bx < p.nb[5] && by == 0) deform_zero_kernel_body(p.za, bx, 0, p.nb[5]);
+}
+
 struct FrameBwdArgs {
     int W, E, TD, max_emb, num_offsets, cam_no;
     int use_stage[2];
@@ -3745,7 +3788,7 @@ static int fwd_pieces(const ed3dgs_deform_cfg *c)
 }
 
 static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
-                     const Workspace &w, bool bwd, hipStream_t s, bool kept = false)
+                     const Workspace &w, bool bwd, hipStream_t s, bool kept = false, const ZeroArgs *zero = nullptr)
 {
     ParamLayout pl = param_layout(c->W, c->TD, c->E, c->n_sh);
     FragLayout fl = frag_layout(c->W, c->E, bwd);
@@ -3765,22 +3808,46 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     }
     const size_t nelem = (size_t)c->W * c->E + (size_t)NHEAD * c->W * c->W + (size_t)NHEAD * OTMAX * 32 * c->W +
                          (size_t)NHEAD * c->W + (size_t)NHEAD * OTMAX * 32;
-    hipLaunchKernelGGL(deform_frag_kernel, dim3((unsigned)((nelem + 255) / 256), 2), dim3(256), 0, s, fa);
+    PrepArgs pa;
+    std::memset(&pa, 0, sizeof pa);
+    pa.fa = fa; pa.fr = fr;
+    if (zero) pa.za = *zero;
+    pa.nb[0] = (int)((nelem + 255) / 256);
     if (c->E == 32 && c->W <= 128) {
         const size_t nch = (size_t)fl.n_chunks * fl.ch_floats;
         const int np = bwd ? 0 : fwd_pieces(c);
         const size_t nch3 = (size_t)fl.n_chunks * (((size_t)(fa.NT + OTMAX) * 1536 + 1023) & ~(size_t)1023);
-        if (np == 3) hipLaunchKernelGGL(deform_chunk_b3_kernel<3>, dim3((unsigned)((nch3 + 255) / 256), 2), dim3(256), 0, s, fa);
-        else if (np == 2) hipLaunchKernelGGL(deform_chunk_b3_kernel<2>, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
-        else hipLaunchKernelGGL(deform_chunk_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+        pa.chunk_pieces = np;
+        pa.nb[1] = (int)(((np == 3 ? nch3 : nch) + 255) / 256);
         if (bwd && kept && use_b3(c))   // the kept-activation data gradient reads its transposed tiles in the b3 format
-            hipLaunchKernelGGL(deform_chunk_b3_bwd_kernel, dim3((unsigned)((nch + 255) / 256), 2), dim3(256), 0, s, fa);
+            pa.nb[2] = (int)((nch + 255) / 256);
         if (bwd && kept && fwd_pieces(c) == 3) {   // ... or, three-piece mode, its own compact chunks
             const size_t nk3 = (size_t)(NHEAD * fa.NT + 1) * ((((size_t)fa.NT + OTMAX) * 1536 + 1023) & ~(size_t)1023);
-            hipLaunchKernelGGL(deform_chunk_kept_kernel<3>, dim3((unsigned)((nk3 + 255) / 256), 2), dim3(256), 0, s, fa);
+            pa.nb[3] = (int)((nk3 + 255) / 256);
         }
     }
-    hipLaunchKernelGGL(deform_frame_kernel, dim3(2), dim3(256), 0, s, fr);
+    if (pa.nb[3]) pa.nb[1] = 0;   // the kept builder writes the chunk region in its own format, all of it
+    pa.nb[4] = 2;
+    pa.nb[5] = zero ? 256 : 0;
+    const int nb_total = pa.nb[0] + pa.nb[1] + pa.nb[2] + pa.nb[3] + pa.nb[4] + pa.nb[5];
+    if (getenv("ED3DGS_PREP_SEQ")) {   // diagnostic: the parts one launch at a time
+        for (int q = 0; q < 6; q++) {
+            if (!pa.nb[q]) continue;
+            PrepArgs one = pa;
+            for (int r = 0; r < 6; r++) if (r != q) one.nb[r] = 0;
+            hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)one.nb[q], 2), dim3(256), 0, s, one);
+        }
+        return check_hip(hipGetLastError(), "deform prep");
+    }
+    if (pa.nb[2]) {   // split-bf16 mode: its builder re-packs tiles of the fp32 chunks in place -> a launch of its own, after them
+        PrepArgs first = pa, second = pa;
+        first.nb[2] = 0;
+        for (int r = 0; r < 6; r++) if (r != 2) second.nb[r] = 0;
+        hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)(nb_total - pa.nb[2]), 2), dim3(256), 0, s, first);
+        hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)pa.nb[2], 2), dim3(256), 0, s, second);
+        return check_hip(hipGetLastError(), "deform prep");
+    }
+    hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)nb_total, 2), dim3(256), 0, s, pa);
     return check_hip(hipGetLastError(), "deform prep");
 }
 
@@ -3902,11 +3969,11 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     if (workspace_bytes < carve(cfg, true, nullptr, nullptr)) { set_error("ed3dgs_deform_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     const ParamLayout pl = param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh);
-    {   // the accumulated outputs start from zero: one launch for the four of them
-        ZeroArgs za;
-        za.p[0] = g_table; za.n[0] = (size_t)cfg->max_embeddings * cfg->TD;
-        za.p[1] = g_offsets; za.n[1] = (size_t)cfg->num_offsets;
-        for (int st = 0; st < 2; st++) { za.p[2 + st] = cfg->use_stage[st] ? gparams[st] : nullptr; za.n[2 + st] = cfg->use_stage[st] ? pl.total : 0; }
+    ZeroArgs za;   // the accumulated outputs start from zero: part of the prepare launch (its own launch only when P == 0)
+    za.p[0] = g_table; za.n[0] = (size_t)cfg->max_embeddings * cfg->TD;
+    za.p[1] = g_offsets; za.n[1] = (size_t)cfg->num_offsets;
+    for (int st = 0; st < 2; st++) { za.p[2 + st] = cfg->use_stage[st] ? gparams[st] : nullptr; za.n[2 + st] = cfg->use_stage[st] ? pl.total : 0; }
+    if (cfg->P == 0) {
         hipLaunchKernelGGL(deform_zero_kernel, dim3(256), dim3(256), 0, s, za);
         if (!check_hip(hipGetLastError(), "zero gradients")) return ED3DGS_ERR_HIP;
     }
@@ -3914,7 +3981,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     if (!embedding || !g_embedding) { set_error("ed3dgs_deform_backward: null embedding pointer"); return ED3DGS_ERR_INVALID; }
     Workspace w;
     carve(cfg, true, workspace, &w);
-    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0)) return ED3DGS_ERR_HIP;
+    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0, &za)) return ED3DGS_ERR_HIP;
     DeformDev d;
     std::memset(&d, 0, sizeof d);
     fill_dev(cfg, d, true);

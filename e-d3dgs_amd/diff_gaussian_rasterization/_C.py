@@ -79,7 +79,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scal
     fopt = dict(dtype=torch.float32, device=dev)
     geo = rc or rd
     run = P != 0
-    mk = lambda c, written: (torch.empty if (written and run) else torch.zeros)((c, H, W), **fopt)
+    def mk(c, written):
+        if written and run:
+            return torch.empty((c, H, W), **fopt)
+        if run:
+            # a plane the variant does not produce (the reference returns freshly filled zeros: 25 MB and a launch each at
+            # 1080p): one zero expanded to the shape.  Reads as zeros everywhere; an in-place write raises instead of aliasing.
+            return torch.zeros((), **fopt).expand(c, H, W)
+        return torch.zeros((c, H, W), **fopt)
     out_color = mk(NUM_CHANNELS, True)
     out_depth, out_mdepth = mk(1, rd), mk(1, rd)
     out_coord, out_mcoord = mk(3, rc), mk(3, rc)

@@ -126,6 +126,11 @@ typedef struct ed3dgs_state_view {
 int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geometry_buffer,
                           const char *binning_buffer, const char *image_buffer, ed3dgs_state_view *out);
 
+/* The scalars train.py logs per rendered frame (train.py:232-244, 300-330: image loss, PSNR), in one launch: out3 = {sum(image *
+ * weight), -10 log10(mean((image - mid)^2)), 1} over n floats -- the vector the multi-GPU path all-reduces.
+ * `acc` = 3 floats of device scratch, zero before the first call; every call leaves them zero.  16-byte aligned inputs. */
+int ed3dgs_image_stats(const float *image, const float *weight, size_t n, float mid, float *acc, float *out3, void *stream);
+
 /* Activations between the deformation network and the rasterizer (gaussian_renderer/__init__.py:77-83;
  * scene/gaussian_model.py:37-45 and, with filter_3D != NULL, :594-603): rot = normalize(rot_raw), scales = exp(s) or
  * sqrt(exp(s)^2 + f^2), opacity = sigmoid(o) [* sqrt(prod exp(s)^2 / prod(exp(s)^2 + f^2))].  Inputs/outputs [P,3],

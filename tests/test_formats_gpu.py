@@ -70,3 +70,27 @@ def test_checkpoint_round_trip_renders_identically(tmp_path):
     for k in ("render", "mask", "expected_depth", "median_depth", "normal", "radii"):
         assert torch.equal(a[k], b[k]), k
     assert float(a["mask"].max()) > 0.5
+
+
+def test_image_stats_matches_torch():
+    """ed3dgs_image_stats (csrc/stats.hip): {sum(image * weight), -10 log10(mean((image - mid)^2)), 1} in one launch, scratch left
+    zero for the next call; odd element counts take the scalar tail."""
+    _need_gpu()
+    import ctypes as C
+    from ed3dgs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acc = torch.zeros(4, device="cuda")
+    for n in (3 * 1080 * 1920, 1027, 4, 3):
+        img = torch.rand(n, generator=g, device="cuda")
+        w = torch.randn(n, generator=g, device="cuda") / n
+        out = torch.full((3,), -1.0, device="cuda")
+        for _ in range(2):                                   # twice: the first call must leave the scratch clean
+            rc = L.ed3dgs_image_stats(C.c_void_p(img.data_ptr()), C.c_void_p(w.data_ptr()), C.c_size_t(n), C.c_float(0.5),
+                                      C.c_void_p(acc.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            want0 = float(torch.dot(img.double(), w.double()))
+            want1 = float(-10.0 * torch.log10((img.double() - 0.5).square().mean()))
+            got = out.cpu().tolist()
+            assert abs(got[0] - want0) <= 1e-5 * max(1e-3, abs(want0)) + 1e-7 and abs(got[1] - want1) <= 1e-4 and got[2] == 1.0
+        assert float(acc.abs().max()) == 0.0
