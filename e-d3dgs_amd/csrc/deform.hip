@@ -880,6 +880,43 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[N], f32x4 *__restr
         if (pipe_n + 2 < pipe_total) GPIPE_ISSUE(pipe_n & 1);                                      \
         pipe_n++;                                                                                  \
     } while (0)
+// Spread issue (round 2).  A 1-KB LDS-DMA piece costs its wave 100-190 cycles to ISSUE when a chunk's nine pieces go out back
+// to back behind the barrier, with all eight waves of the CU doing the same (measured with in-kernel timers: 1700 of a tile's
+// 6400 cycles), and ~60 among MFMAs.  So a tile issues the pieces of the chunk AFTER NEXT one or two at a time between its own
+// k-tiles' MFMAs (GPIPE_SPREAD_BEGIN once per tile, GPIPE_PIECES(first, count) between the products), and the barrier at the tile's
+// end is preceded by a COUNTED wait: the pieces are older than the tile's kept-activation stores (vmcnt retires in order), so
+// s_waitcnt vmcnt(<number of those stores>) has the chunk landed while the stores stay in flight (GPIPE_SYNC(stores)).
+// `stores` must not exceed the vector-memory operations the wave really issues after its last piece (fewer = a longer wait, never
+// a wrong one): 4 with activations kept and at least one valid Gaussian in the wave, else 0.
+#define GPIPE_SPREAD_BEGIN()                                                                       \
+    /* every tile issues nine pieces, unconditionally, so that the compiler can COUNT them (pieces behind a branch make \
+       it wait for vmcnt(0) on the tile's bias loads, i.e. for the pieces themselves): past the last chunk the pieces \
+       re-read chunk 0 into the buffer nobody reads any more */                                     \
+    const float *gsp_src_ = (pipe_n + 1 < pipe_total) ? pipe_seq.next(d) : d.frag[d.use_stage[0] ? 0 : 1] + d.fl.CH; \
+    float *gsp_dst_ = wl + ((pipe_n + 1) & 1) * PIPE_CHF;
+#define GPIPE_PIECES(first_, count_)                                                               \
+    do {                                                                                           \
+        _Pragma("unroll") for (int i_ = (first_); i_ < (first_) + (count_) && i_ < PIPE_NI; i_++)  \
+            __builtin_amdgcn_global_load_lds(                                                      \
+                (const __attribute__((address_space(1))) void *)(gsp_src_ + (i_ * 4 + wave) * 256 + lane * 4), \
+                (__attribute__((address_space(3))) void *)(gsp_dst_ + (i_ * 4 + wave) * 256), 16, 0, 0); \
+    } while (0)
+// spread kernels start with chunk 0 only: tile m issues chunk m + 1 itself
+#define GPIPE_START_SPREAD(total_, ...)                                                            \
+    do {                                                                                           \
+        pipe_seq.init(d, ##__VA_ARGS__); pipe_n = 0; pipe_total = (total_);                        \
+        if (pipe_total > 0) GPIPE_ISSUE(0);                                                        \
+        __syncthreads();                                                                           \
+    } while (0)
+#define GPIPE_SYNC_N(have_stores_, n_)                                                             \
+    do {                                                                                           \
+        /* wait + barrier as ONE opaque statement: __syncthreads() would make the compiler drain vmcnt(0) in front of it \
+           (pending LDS-DMA), i.e. wait for the stores just issued as well */                       \
+        if (have_stores_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n_) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
+        pipe_n++;                                                                                  \
+    } while (0)
+#define GPIPE_SYNC(stores4_) GPIPE_SYNC_N(stores4_, 4)
 #define PIPE_LOAD() stage_load<PIPE_NF4>(pipe_st, reinterpret_cast<const f32x4 *>(pipe_seq.next(d)), tid)
 #define PIPE_COMMIT(buf_) stage_store<PIPE_NF4>(pipe_st, reinterpret_cast<f32x4 *>(wl + (buf_) * PIPE_CHF), tid)
 #define PIPE_CUR() (wl + (pipe_n & 1) * PIPE_CHF)
@@ -1219,6 +1256,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 {
     constexpr int TS = NP * 512;   // floats per weight tile in the chunk
     extern __shared__ float wl[];
+    // The stage's biases (head hidden, head output, trunk: one contiguous run of the fragment workspace) live in LDS for the
+    // stage: with them fetched from global memory per tile, the tile's only way to wait for them was vmcnt(0) -- the compiler
+    // does not count past LDS-DMA operations -- which is a wait for the chunk pieces issued among the tile's MFMAs
+    constexpr int NBIAS = NHEAD * 32 * NT + NHEAD * OTMAX * 32 + 32 * NT;
+    __shared__ float bias_s[NBIAS];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_bi = (d.P + 127) / 128;
@@ -1242,12 +1284,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const bool timed = d.timing != nullptr && blockIdx.x == 0;
 #define FW_MARK(i_) do { if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tph[i_] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
     ED3_GPIPE(NT, TS)
-    GPIPE_START(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
+    GPIPE_START_SPREAD(my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0), my_full, tail_k);
     for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
         const int bi = (it < my_full) ? b + it * G : tail_bi;
         const int konly = (it < my_full) ? -1 : tail_k;
         const int g_raw = bi * 128 + wave * 32 + (lane & 31);
         const bool gvalid = g_raw < d.P;
+        const bool wave_stores = d.keep && (bi * 128 + wave * 32 < d.P);   // wave-uniform: its kept-activation stores are issued
         const int g = gvalid ? g_raw : d.P - 1;
         float cx[3], cs[3], cr[4], co, csh[24];
 #pragma unroll
@@ -1266,6 +1309,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int s = 0; s < 2; s++) {
             if (d.use_stage[s]) {
                 const float *fr = d.frag[s];
+                for (int e = tid; e < NBIAS; e += 256) bias_s[e] = fr[d.fl.B2 + e];   // B2 | B3 | HB, as frag_layout orders them
+                __syncthreads();   // (the previous stage's last tile ended with a barrier: nobody still reads the old values)
+                const float *bias_hb = bias_s + (d.fl.HB - d.fl.B2), *bias_b2 = bias_s, *bias_b3 = bias_s + (d.fl.B3 - d.fl.B2);
                 unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
                 XSplitN<NP> as[NT];
                 {
@@ -1275,10 +1321,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     XSplitN<NP> ebs;
                     split_tile_n<NP>(eb[0], ebs);
                     const float *wb = PIPE_CUR();
+                    GPIPE_SPREAD_BEGIN()
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
                         f32x4 bv[4];
-                        load_bias4(bv, fr + d.fl.HB, nt, h);
+                        load_bias4(bv, bias_hb, nt, h);
+                        GPIPE_PIECES(nt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
                         const f32x16 acc = gemm_tile_bn<NP>(wb + nt * TS, ebs, zero_acc(), lane);
                         float av[16];
 #pragma unroll
@@ -1287,7 +1335,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         if (d.keep) mka |= (unsigned long long)mask16(av) << (16 * nt);
                         split_tile_n<NP>(av, as[nt]);
                     }
-                    GPIPE_ADVANCE();
+                    GPIPE_SYNC(wave_stores);
                 }
                 if (d.keep && gvalid) d.MK[s][((size_t)g) * 2 + h] = mka;
                 for (int k = 0; k < NHEAD; k++) {
@@ -1306,13 +1354,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             if (timed) { tlast = clock64(); ntile++; }
                             const float *wb = PIPE_CUR();
                             f32x4 bv[4];
-                            load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                            load_bias4(bv, bias_b2 + k * d.W, nt, h);
                             f32x16 acc = zero_acc();
+                            GPIPE_SPREAD_BEGIN()
 #pragma unroll
-                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
+                            for (int kt = 0; kt < NT; kt++) {
+                                acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
+                                GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
+                            }
                             FW_MARK(0);
-                            if (timed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                            FW_MARK(1);
                             // the 16 W3 values of this lane are fetched from LDS in one go, ahead of the epilogue's VALU
                             // work: read-wait-MFMA per k-slot (what the compiler emits for the plain loop) is a chain of
                             // 16 LDS latencies, as long as the tile's 64 big MFMAs
@@ -1335,12 +1385,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 yn2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk + 1], z[0][kk + 1], yn2, 0, 0, 0);
                             }
                             FW_MARK(3);
-                            if (timed) { __syncthreads(); FW_MARK(4); if (pipe_n + 2 < pipe_total) GPIPE_ISSUE(pipe_n & 1); pipe_n++; FW_MARK(5); }
-                            else
-                            GPIPE_ADVANCE();
+                            GPIPE_SYNC(wave_stores);
+                            FW_MARK(4);
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
-                        const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+                        const float *b3 = bias_b3 + k * OTMAX * 32;
                         float yo[4];
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const float ys = yn[i] + yn2[i]; yo[i] = (ys + __shfl_xor(ys, 32) + b3[i]) * hc; }  // the two feature halves
@@ -1359,10 +1408,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         for (int nt = 0; nt < NT; nt++) {
                             const float *wb = PIPE_CUR();
                             f32x4 bv[4];
-                            load_bias4(bv, fr + d.fl.B2 + (size_t)k * d.W, nt, h);
+                            load_bias4(bv, bias_b2 + k * d.W, nt, h);
                             f32x16 acc = zero_acc();
+                            GPIPE_SPREAD_BEGIN()
 #pragma unroll
-                            for (int kt = 0; kt < NT; kt++) acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
+                            for (int kt = 0; kt < NT; kt++) {
+                                acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
+                                GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
+                            }
                             float z[1][16];
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
@@ -1372,11 +1425,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             split_tile_n<NP>(z[0], zs);
                             y[0] = gemm_tile_bn<NP>(wb + NT * TS, zs, y[0], lane);
                             if (nout > 1) y[1] = gemm_tile_bn<NP>(wb + (NT + 1) * TS, zs, y[1], lane);
-                            GPIPE_ADVANCE();
+                            GPIPE_SYNC(wave_stores);
                         }
                         if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
                         {   // head output bias, after the contraction (see load_bias4)
-                            const float *b3 = fr + d.fl.B3 + (size_t)k * OTMAX * 32;
+                            const float *b3 = bias_b3 + k * OTMAX * 32;
 #pragma unroll
                             for (int ot = 0; ot < OTMAX; ot++) {
                                 if (ot < nout) {
@@ -1945,12 +1998,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int PIPE_NI = PIPE_CHF / 1024;
     ChunkSeqKept<NT, TS> pipe_seq;
     int pipe_n = 0, pipe_total = 0;
-    GPIPE_START(my_full * per_iter + (has_tail ? n_en * NT + 1 : 0), my_full, tail_s);
+    GPIPE_START_SPREAD(my_full * per_iter + (has_tail ? n_en * NT + 1 : 0), my_full, tail_s);
     for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
         const int bi = (it < my_full) ? b + it * G : tail_bi;
         const int sonly = (it < my_full) ? -1 : tail_s;
         const int g_raw = bi * 128 + wave * 32 + (lane & 31);
         const bool gvalid = g_raw < d.P;
+        const bool wave_valid = bi * 128 + wave * 32 < d.P;   // wave-uniform: the wave's g_hid stores are issued
         const int g = gvalid ? g_raw : d.P - 1;
         f32x16 ge;
 #pragma unroll
@@ -2035,22 +2089,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int r = 0; r < 16; r++) z[0][r] = (mkz >> (16 * nt + r)) & 1ull ? acc[r] : 0.f;
                     XSplitN<NP> zs;
                     split_tile_n<NP>(z[0], zs);
+                    // the next chunk's pieces go out between this tile's products (see GPIPE_SPREAD_BEGIN); no stores in a tile
+                    GPIPE_SPREAD_BEGIN()
 #pragma unroll
-                    for (int i2 = 0; i2 < NT; i2++) ga[i2] = gemm_tile_bn<NP>(wb + (OTMAX + i2) * TS, zs, ga[i2], lane);
-                    GPIPE_ADVANCE();
+                    for (int i2 = 0; i2 < NT; i2++) {
+                        GPIPE_PIECES(i2 * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
+                        ga[i2] = gemm_tile_bn<NP>(wb + (OTMAX + i2) * TS, zs, ga[i2], lane);
+                    }
+                    GPIPE_SYNC_N(false, 0);
                 }
             }
+            {
+                GPIPE_SPREAD_BEGIN()
+                GPIPE_PIECES(0, PIPE_NI);   // all of them ahead of the g_hid stores: 4 stores per tile follow the last piece
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                float gh[16];
+                for (int nt = 0; nt < NT; nt++) {
+                    float gh[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) gh[r] = (mka >> (16 * nt + r)) & 1ull ? ga[nt][r] : 0.f;
-                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh);
-                XSplitN<NP> ghs;
-                split_tile_n<NP>(gh, ghs);
-                ge = gemm_tile_bn<NP>(PIPE_CUR() + nt * TS, ghs, ge, lane);
+                    for (int r = 0; r < 16; r++) gh[r] = (mka >> (16 * nt + r)) & 1ull ? ga[nt][r] : 0.f;
+                    if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh);
+                    XSplitN<NP> ghs;
+                    split_tile_n<NP>(gh, ghs);
+                    ge = gemm_tile_bn<NP>(PIPE_CUR() + nt * TS, ghs, ge, lane);
+                }
+                GPIPE_SYNC_N(wave_valid, 4 * NT);
             }
-            GPIPE_ADVANCE();
         }
         if (gvalid) {
             if (sonly >= 0) {   // tail unit: one of two addends into rows the host zeroed
@@ -3939,7 +4002,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         hipLaunchKernelGGL((deform_forward_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
     });
     if (pf) prof_stop(ED3DGS_PROF_DEFORM_FORWARD, s);
-    if (d.timing) {   // diagnostic: narrow-head tile loop of block 0 (0 weights + MFMAs, 1 vmcnt wait, 2 epilogue + kept stores, 3 output MFMAs, 4 barrier, 5 DMA issue)
+    if (d.timing) {   // diagnostic: narrow-head tile loop of block 0 (0 weights + MFMAs + DMA pieces, 2 epilogue + kept stores, 3 output MFMAs, 4 counted wait + barrier)
         unsigned long long t[32];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(t, d.timing, sizeof t, hipMemcpyDeviceToHost);
