@@ -344,7 +344,7 @@ def main():
     _C.LAST.clear()
 
     # ---- per-kernel table: an instrumented, UNTIMED pass (five event pairs per step cost stream time) ----
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0xFF))
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0xFF | (1 << 30)))   # + K7 work counts (this pass only)
     for k in range(a.steps):
         step(item_at(k))
     step.drain()
@@ -353,6 +353,9 @@ def main():
     tab_ms, tab_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(tab_ms, tab_n)
     tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(NS)]
+    k7_counts = (ctypes.c_ulonglong * 4)()
+    L.ed3dgs_profile_tile_backward_counts(k7_counts)
+    k7_work = [k7_counts[i] / max(tab_n[1], 1) for i in range(4)]   # per launch: iterations, pairs, staged, kept
     dom = max([i for i in range(NS) if i != 4], key=lambda i: tab_avg[i])   # the dominant single KERNEL
 
     # ---- timed: exactly K steps; events only around the dominant kernel and K7 ----
@@ -482,11 +485,26 @@ def main():
                            "TFLOPs_fp32_equivalent": tfl(mac, tab_avg[sl]),
                            "matrix_pipe": "bf16 (%d exact piece products per multiply)" % pr if pr > 1 else "f32"}
         kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
+    # K7 against the vector-ALU roof: its inner loop issues K7_VALU_PER_ITER vector instructions per visited (tile, Gaussian)
+    # iteration (counted in the ISA of render_backward_kernel<false,true>: 211 at 4 issue cycles + 8 transcendentals at 8), a
+    # SIMD issues one per cycle, 1024 SIMDs at 2.4 GHz; iterations and blended pairs are COUNTED by the kernel in the
+    # instrumented pass (popcount of the valid masks), the time is that pass's launch time with the counting on
+    K7_ISSUE_CYCLES_PER_ITER = 211 * 4 + 8 * 8
+    it_per_s = k7_work[0] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0   # counts are per item (deterministic); time = the timed region's launches
+    valu_roof = {"visited_iterations_per_launch": k7_work[0], "blended_pairs_per_launch": k7_work[1],
+                 "list_entries_staged_per_launch": k7_work[2], "entries_kept_by_tile_reject_per_launch": k7_work[3],
+                 "pairs_per_iteration": k7_work[1] / k7_work[0] if k7_work[0] else 0.0,
+                 "issue_cycles_per_iteration": K7_ISSUE_CYCLES_PER_ITER, "iterations_per_s": it_per_s,
+                 "roof_iterations_per_s": 1024 * 2.4e9 / K7_ISSUE_CYCLES_PER_ITER,
+                 "frac": it_per_s * K7_ISSUE_CYCLES_PER_ITER / (1024 * 2.4e9), "pairs_per_s": k7_work[1] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
+                 "note": "vector-instruction issue cycles the visited iterations need / cycles the 1024 SIMDs offer in the launch; the "
+                         "counting pass itself runs K7 slower (%.3f ms per launch: ballots per entry) and is not the time used" % tab_avg[1]}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                "traffic": pmc.get("render_backward_kernel<false,true>"), "traffic_source": traffic_source,
                "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1],
                "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
+               "valu_roof": valu_roof,
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
                        "reported as defined there, next to the pair rate"}
     if dom >= 2 and dm:

@@ -50,6 +50,7 @@ ImageState ImageState::from_chunk(char *&chunk, size_t N, size_t T)
     obtain(chunk, img.accum_coord, N * 3, 128);
     obtain(chunk, img.accum_depth, N, 128);
     obtain(chunk, img.normal_length, N, 128);
+    obtain(chunk, img.tile_order, T, 128);
     return img;
 }
 BinningState BinningState::from_chunk(char *&chunk, size_t R)
@@ -83,6 +84,8 @@ struct Profiler {
     unsigned mask = 0;
     int n[ED3DGS_PROF_SLOTS] = {0};
     std::vector<hipEvent_t> e0[ED3DGS_PROF_SLOTS], e1[ED3DGS_PROF_SLOTS];
+    unsigned long long *counters = nullptr;   // device: K7's visited-iteration / pair / staged / kept counts while its slot is timed
+    unsigned long long counters_host[4] = {0, 0, 0, 0};
 };
 static Profiler g_prof;
 bool prof_start(int slot, hipStream_t s)
@@ -171,6 +174,8 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!ok("sort")) return ED3DGS_ERR_HIP;
     launch_identify_tile_ranges(R, bin.tile_keys, img.ranges, s);
     if (!ok("identifyTileRanges")) return ED3DGS_ERR_HIP;
+    launch_tile_order((int)T, img.ranges, img.tile_order, s);
+    if (!ok("tileOrder")) return ED3DGS_ERR_HIP;
 
     return R;
 }
@@ -303,7 +308,7 @@ int ed3dgs_rasterize_backward(
         launch_render_backward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
                                background, require_coord != 0, require_depth != 0, alphas, normalmap, img, dL_dpix,
                                dL_dpix_coord, dL_dpix_mcoord, dL_dpix_depth, dL_dpix_mdepth, dL_dalphas,
-                               dL_dpix_normal, grec, grec_coord, s);
+                               dL_dpix_normal, grec, grec_coord, s, pb ? g_prof.counters : nullptr);
         if (pb) prof_stop(ED3DGS_PROF_TILE_BACKWARD, s);
         if (!ok("render backward")) return ED3DGS_ERR_HIP;
     }
@@ -380,6 +385,10 @@ int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask)
             v->resize(max_samples);
             for (auto &e : *v) if (!check_hip(hipEventCreate(&e), "hipEventCreate")) return ED3DGS_ERR_HIP;
         }
+    if ((slot_mask >> ED3DGS_PROF_TILE_BACKWARD & 1u) && (slot_mask & ED3DGS_PROF_COUNT_WORK)) {   // counting costs K7 a few ballots per entry
+        if (!check_hip(hipMalloc((void **)&g_prof.counters, 4 * sizeof(unsigned long long)), "counter buffer") ||
+            !check_hip(hipMemset(g_prof.counters, 0, 4 * sizeof(unsigned long long)), "counter buffer")) return ED3DGS_ERR_HIP;
+    }
     g_prof.on = true;
     return 0;
 }
@@ -388,6 +397,15 @@ int ed3dgs_profile_end_slots(double *ms_total, int *launches)
 {
     if (!g_prof.on) { set_error("ed3dgs_profile_end: not active"); return ED3DGS_ERR_INVALID; }
     g_prof.on = false;
+    static unsigned long long last_counters[4];
+    if (g_prof.counters) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(last_counters, g_prof.counters, sizeof last_counters, hipMemcpyDeviceToHost);
+        (void)hipFree(g_prof.counters);
+        g_prof.counters = nullptr;
+    } else {
+        std::memset(last_counters, 0, sizeof last_counters);
+    }
     for (int k = 0; k < ED3DGS_PROF_SLOTS; k++) {
         double t = 0;
         for (int i = 0; i < g_prof.n[k]; i++) {
@@ -401,6 +419,14 @@ int ed3dgs_profile_end_slots(double *ms_total, int *launches)
         for (auto *v : {&g_prof.e0[k], &g_prof.e1[k]}) for (auto &e : *v) (void)hipEventDestroy(e);
     }
     g_prof = Profiler();
+    std::memcpy(g_prof.counters_host, last_counters, sizeof last_counters);
+    return 0;
+}
+
+int ed3dgs_profile_tile_backward_counts(unsigned long long out4[4])
+{
+    if (!out4) { set_error("ed3dgs_profile_tile_backward_counts: null pointer"); return ED3DGS_ERR_INVALID; }
+    std::memcpy(out4, g_prof.counters_host, 4 * sizeof(unsigned long long));
     return 0;
 }
 

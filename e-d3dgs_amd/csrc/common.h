@@ -51,6 +51,7 @@ struct ImageState {
     float *accum_coord;    // [3][H][W]
     float *accum_depth;    // [H][W]
     float *normal_length;  // [H][W]
+    uint32_t *tile_order;  // [T] tile ids, longest tile list first: the order in which the tile kernels' blocks take tiles
     static ImageState from_chunk(char *&chunk, size_t N, size_t T);
 };
 struct BinningState {
@@ -83,6 +84,7 @@ void launch_mark_visible(int P, const float *means, const float *view, uint8_t *
 void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint32_t *tile_keys,
                                 uint32_t *values, hipStream_t s);
 void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ranges, hipStream_t s);
+void launch_tile_order(int T, const uint32_t *ranges, uint32_t *tile_order, hipStream_t s);
 void launch_compose_keys(int R, const uint32_t *tile_keys, const uint32_t *point_list, const float *depths,
                          uint64_t *keys, hipStream_t s);
 size_t scan_temp_bytes(int P);
@@ -105,7 +107,7 @@ void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t
                             bool depth, const float *alphas, const float *normalmap, ImageState img,
                             const float *dL_dpix, const float *dL_dcoord, const float *dL_dmcoord,
                             const float *dL_ddepth, const float *dL_dmdepth, const float *dL_dalpha,
-                            const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s);
+                            const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s, unsigned long long *counters = nullptr);
 // integrate.hip (point integration: K12-K14)
 size_t integrate_point_bytes(int PN, int width, int height);
 size_t integrate_workspace_bytes(int R, int width, int height);

@@ -322,6 +322,40 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
     if (idx == L - 1) ranges[2 * currtile + 1] = L;
 }
 
+// Tile order for the tile kernels (K6, K7): one wave per tile, 8,160 tiles at 1080p over ~3,000 resident waves, and the lists
+// are longest in the middle of the image -- in index order the longest tiles start mid-way and finish alone (a simulation
+// of the C3 frame: makespan 897 vs 689 list entries per slot).  Blocks take tiles longest list first instead: a counting sort
+// of the tile ids by list length (buckets of 8 entries, descending), one block, LDS histogram.  Only the ORDER in which
+// tiles are processed changes; every tile's result is its own.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t hist[256], cursor[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint2 r = ranges[t];
+        atomicAdd(&hist[255 - min(255u, (r.y - r.x) >> 3)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of the 256 buckets by one wave: 4 per lane + a wave scan
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = hist[4 * tid + i]; sum += v[i]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o); if (tid >= o) inc += n; }
+        uint32_t base = inc - sum;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cursor[4 * tid + i] = base; base += v[i]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint2 r = ranges[t];
+        order[atomicAdd(&cursor[255 - min(255u, (r.y - r.x) >> 3)], 1u)] = (uint32_t)t;
+    }
+}
+
 // the reference's 64-bit sort keys, for the parity tests' state view only
 __global__ void __launch_bounds__(256) compose_keys_kernel(int L, const uint32_t *__restrict__ tile_keys,
                                                            const uint32_t *__restrict__ point_list,
@@ -369,6 +403,12 @@ void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ran
 {
     if (R <= 0) return;
     hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, ranges);
+}
+
+void launch_tile_order(int T, const uint32_t *ranges, uint32_t *tile_order, hipStream_t s)
+{
+    if (T <= 0) return;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, T, reinterpret_cast<const uint2 *>(ranges), tile_order);
 }
 
 void launch_compose_keys(int R, const uint32_t *tile_keys, const uint32_t *point_list, const float *depths,

@@ -77,22 +77,25 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[NV], int lane)
 
 template <bool COORD, bool DEPTH>
 __global__ void __launch_bounds__(64) render_backward_kernel(
-    int W, int H, int gx, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+    int W, int H, int gx, const uint32_t *__restrict__ tile_order, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, const float4 *__restrict__ rec_coord, float focal_x, float focal_y,
     const float *__restrict__ bg, const float *__restrict__ alphas, const float *__restrict__ normalmap,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ accum_coord,
     const float *__restrict__ accum_depth, const float *__restrict__ normal_length,
     const float *__restrict__ dL_dpix, const float *__restrict__ dL_dcoord, const float *__restrict__ dL_dmcoord,
     const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dmdepth, const float *__restrict__ dL_dalpha,
-    const float *__restrict__ dL_dnormal, float *__restrict__ grec, float *__restrict__ grec_coord)
+    const float *__restrict__ dL_dnormal, float *__restrict__ grec, float *__restrict__ grec_coord,
+    unsigned long long *__restrict__ counters)   // measurement only (bench.py): [0] visited (tile, Gaussian) iterations, [1] blended
+                                                  // pairs, [2] staged list entries, [3] entries kept by the tile-level reject; NULL = off
 {
     constexpr bool GEO = COORD || DEPTH;
     constexpr int NV = COORD ? 32 : 16;
+    unsigned n_iter = 0, n_pair = 0, n_staged = 0, n_kept = 0;
     __shared__ float4 s_rec[64 * 4];
     __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
     __shared__ uint32_t s_id[64];
 
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];   // longest tile lists first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int px0 = tx * TILE + (lane & 3) * 4;
@@ -246,6 +249,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         __syncthreads();
         // entries that cannot reach alpha >= 1/255 anywhere in the tile are never visited (raster_common.h)
         unsigned long long live = __ballot(keep);
+        if (counters) { n_staged += (unsigned)cnt; n_kept += (unsigned)__popcll(live); }
         while (live) {
             const int j = __builtin_ctzll(live);
             live &= live - 1;
@@ -272,6 +276,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                 med[p] = vd && (k + 1u == maxc[p]);
             }
             if (!__any(any_valid)) continue;
+            if (counters) {
+                n_iter++;
+#pragma unroll
+                for (int p = 0; p < 4; p++) n_pair += (unsigned)__popcll(__ballot(alpha[p] > 0.f));
+            }
 
             const float4 r2 = s_rec[j * 4 + 2];  // b, tongue, ts, rpx
             float4 r3 = make_float4(0, 0, 0, 0); // rpy, nx, ny, nz
@@ -391,6 +400,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             }
         }
     }
+    if (counters && lane == 0) {
+        atomicAdd(counters + 0, (unsigned long long)n_iter); atomicAdd(counters + 1, (unsigned long long)n_pair);
+        atomicAdd(counters + 2, (unsigned long long)n_staged); atomicAdd(counters + 3, (unsigned long long)n_kept);
+    }
 }
 
 void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
@@ -398,16 +411,16 @@ void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t
                             bool depth, const float *alphas, const float *normalmap, ImageState img,
                             const float *dL_dpix, const float *dL_dcoord, const float *dL_dmcoord,
                             const float *dL_ddepth, const float *dL_dmdepth, const float *dL_dalpha,
-                            const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s)
+                            const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s, unsigned long long *counters)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     dim3 grid(gx * gy), block(64);
 #define ED3_BWD(C_, D_)                                                                                              \
-    hipLaunchKernelGGL((render_backward_kernel<C_, D_>), grid, block, 0, s, W, H, gx,                                \
+    hipLaunchKernelGGL((render_backward_kernel<C_, D_>), grid, block, 0, s, W, H, gx, img.tile_order,                             \
                        reinterpret_cast<const uint2 *>(ranges), point_list, reinterpret_cast<const float4 *>(rec),  \
                        reinterpret_cast<const float4 *>(rec_coord), focal_x, focal_y, bg, alphas, normalmap,         \
                        img.n_contrib, img.accum_coord, img.accum_depth, img.normal_length, dL_dpix, dL_dcoord,       \
-                       dL_dmcoord, dL_ddepth, dL_dmdepth, dL_dalpha, dL_dnormal, grec, grec_coord)
+                       dL_dmcoord, dL_ddepth, dL_dmdepth, dL_dalpha, dL_dnormal, grec, grec_coord, counters)
     if (coord && depth) ED3_BWD(true, true);
     else if (coord) ED3_BWD(true, false);
     else if (depth) ED3_BWD(false, true);

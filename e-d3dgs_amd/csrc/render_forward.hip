@@ -8,7 +8,7 @@ namespace ed3 {
 
 template <bool COORD, bool DEPTH>
 __global__ void __launch_bounds__(64) render_forward_kernel(
-    int W, int H, int gx, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+    int W, int H, int gx, const uint32_t *__restrict__ tile_order, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, const float4 *__restrict__ rec_coord, float focal_x, float focal_y,
     const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_coord,
     float *__restrict__ out_mcoord, float *__restrict__ out_depth, float *__restrict__ out_mdepth,
@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
     __shared__ float4 s_rec[64 * 4];
     __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
 
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];   // longest tile lists first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int px0 = tx * TILE + (lane & 3) * 4;
@@ -220,7 +220,7 @@ void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t 
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     dim3 grid(gx * gy), block(64);
 #define ED3_FWD(C_, D_)                                                                                              \
-    hipLaunchKernelGGL((render_forward_kernel<C_, D_>), grid, block, 0, s, W, H, gx,                                 \
+    hipLaunchKernelGGL((render_forward_kernel<C_, D_>), grid, block, 0, s, W, H, gx, img.tile_order,                              \
                        reinterpret_cast<const uint2 *>(ranges), point_list, reinterpret_cast<const float4 *>(rec),  \
                        reinterpret_cast<const float4 *>(rec_coord), focal_x, focal_y, bg, out_color, out_coord,      \
                        out_mcoord, out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img.n_contrib,          \

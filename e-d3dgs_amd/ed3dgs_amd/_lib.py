@@ -52,7 +52,7 @@ def lib():
         getattr(L, n).restype = C.c_size_t
     for n in ("ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible", "ed3dgs_state_view_get",
               "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
-              "ed3dgs_activations_backward", "ed3dgs_compute_3d_filter", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours", "ed3dgs_integrate", "ed3dgs_image_stats"):
+              "ed3dgs_activations_backward", "ed3dgs_compute_3d_filter", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts"):
         getattr(L, n).restype = C.c_int
     _lib = L
     return L
@@ -65,7 +65,7 @@ EXPORTS = (
     "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
     "ed3dgs_activations_backward", "ed3dgs_filter3d_workspace_bytes", "ed3dgs_compute_3d_filter",
     "ed3dgs_knn_workspace_bytes", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours",
-    "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes", "ed3dgs_integrate", "ed3dgs_image_stats")
+    "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts")
 
 
 def last_error():

@@ -202,6 +202,10 @@ int ed3dgs_knn_neighbours(int P, int K, const float *points, float *sq_dists, in
  * hipEvents on the stream they are launched on; ed3dgs_profile_end synchronises those events and returns the summed
  * kernel durations in milliseconds and the launch counts.  Not part of the data path. */
 int ed3dgs_profile_begin(int max_samples);
+/* Work counts of the tile backward (K7) over the launches the last ed3dgs_profile_begin_slots .. _end_slots bracket timed with its
+ * slot and ED3DGS_PROF_COUNT_WORK on: out4 = {visited (tile, Gaussian) iterations, blended pixel-Gaussian pairs, list entries staged, entries kept by the
+ * tile-level reject}.  Measurement only: bench.py prices K7 against the VALU roof with them. */
+int ed3dgs_profile_tile_backward_counts(unsigned long long out4[4]);
 int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches);
 /* Same, for every timed kernel: arrays of ED3DGS_PROF_SLOTS entries indexed by the slots below. */
 enum {
@@ -213,7 +217,8 @@ enum {
     ED3DGS_PROF_DEFORM_WGRAD_TRUNK = 5,  /* ... of which: deform_wgrad_kernel (dW1 / db1) */
     ED3DGS_PROF_DEFORM_WGRAD_WIDE = 6,   /* ... the wide (SH) head's launch(es) */
     ED3DGS_PROF_DEFORM_WGRAD_NARROW = 7, /* ... the narrow heads' launch */
-    ED3DGS_PROF_SLOTS = 8
+    ED3DGS_PROF_SLOTS = 8,
+    ED3DGS_PROF_COUNT_WORK = 1 << 30   /* flag in the slot mask: also count K7's work (ed3dgs_profile_tile_backward_counts) */
 };
 int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask);  /* bit k = time slot k; every event pair costs
                                                                         * stream time, so time few kernels at once */
