@@ -344,7 +344,7 @@ def main():
     _C.LAST.clear()
 
     # ---- per-kernel table: an instrumented, UNTIMED pass (five event pairs per step cost stream time) ----
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0xFF | (1 << 30)))   # + K7 work counts (this pass only)
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0xFF))
     for k in range(a.steps):
         step(item_at(k))
     step.drain()
@@ -353,9 +353,19 @@ def main():
     tab_ms, tab_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(tab_ms, tab_n)
     tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(NS)]
+    # K7's work counts (visited iterations, blended pairs, ...): a short pass of its own -- counting slows the kernel down
+    n_count = min(4, a.steps)
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(n_count + 2), ctypes.c_uint(2 | (1 << 30)))
+    for k in range(n_count):
+        step(item_at(k))
+    step.drain()
+    torch.cuda.synchronize()
+    cnt_ms, cnt_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
+    L.ed3dgs_profile_end_slots(cnt_ms, cnt_n)
     k7_counts = (ctypes.c_ulonglong * 4)()
     L.ed3dgs_profile_tile_backward_counts(k7_counts)
-    k7_work = [k7_counts[i] / max(tab_n[1], 1) for i in range(4)]   # per launch: iterations, pairs, staged, kept
+    k7_work = [k7_counts[i] / max(cnt_n[1], 1) for i in range(4)]   # per launch: iterations, pairs, staged, kept
+    k7_count_ms = cnt_ms[1] / max(cnt_n[1], 1)
     dom = max([i for i in range(NS) if i != 4], key=lambda i: tab_avg[i])   # the dominant single KERNEL
 
     # ---- timed: exactly K steps; events only around the dominant kernel and K7 ----
@@ -498,7 +508,7 @@ def main():
                  "roof_iterations_per_s": 1024 * 2.4e9 / K7_ISSUE_CYCLES_PER_ITER,
                  "frac": it_per_s * K7_ISSUE_CYCLES_PER_ITER / (1024 * 2.4e9), "pairs_per_s": k7_work[1] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                  "note": "vector-instruction issue cycles the visited iterations need / cycles the 1024 SIMDs offer in the launch; the "
-                         "counting pass itself runs K7 slower (%.3f ms per launch: ballots per entry) and is not the time used" % tab_avg[1]}
+                         "counts from a separate pass over the first %d items (counting slows K7 to %.3f ms per launch; that is not the time used)" % (n_count, k7_count_ms)}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                "traffic": pmc.get("render_backward_kernel<false,true>"), "traffic_source": traffic_source,

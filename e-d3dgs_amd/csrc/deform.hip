@@ -211,11 +211,15 @@ __device__ __forceinline__ void deform_frame_kernel_body(const FrameArgs &a, con
     const float *W1 = a.params[s] + a.W1_off;
     const float *b1 = a.params[s] + a.b1_off;
     const int ld = TD + a.E;
-    for (int o = threadIdx.x; o < a.W; o += blockDim.x) {
-        float acc = b1[o];
+    // lanes along the row (coalesced reads of W1; a thread per output walked its own 1152-byte-strided row: 10 us of a 15-us launch)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
+    for (int o = wv; o < a.W; o += nwv) {
         const float *w = W1 + (size_t)o * ld;
-        for (int j = 0; j < TD; j++) acc += w[j] * sh_h[j];
-        a.hb[s][o] = acc;
+        float acc = 0.f;
+        for (int j = ln; j < TD; j += 64) acc += w[j] * sh_h[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (ln == 0) a.hb[s][o] = acc + b1[o];
     }
 }
 __global__ void __launch_bounds__(256) deform_frame_kernel(FrameArgs a) { deform_frame_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }

@@ -276,10 +276,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                 med[p] = vd && (k + 1u == maxc[p]);
             }
             if (!__any(any_valid)) continue;
-            if (counters) {
+            if (counters) {   // per lane; summed over the wave once, at the end of the tile
                 n_iter++;
-#pragma unroll
-                for (int p = 0; p < 4; p++) n_pair += (unsigned)__popcll(__ballot(alpha[p] > 0.f));
+                n_pair += (alpha[0] > 0.f) + (alpha[1] > 0.f) + (alpha[2] > 0.f) + (alpha[3] > 0.f);
             }
 
             const float4 r2 = s_rec[j * 4 + 2];  // b, tongue, ts, rpx
@@ -399,6 +398,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                 atomicAdd(grec_coord + (size_t)id * GREC + (lane - 16), z);
             }
         }
+    }
+    if (counters) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n_pair += (unsigned)__shfl_xor((int)n_pair, off);
     }
     if (counters && lane == 0) {
         atomicAdd(counters + 0, (unsigned long long)n_iter); atomicAdd(counters + 1, (unsigned long long)n_pair);

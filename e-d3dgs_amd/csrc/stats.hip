@@ -12,12 +12,19 @@ __global__ void __launch_bounds__(256) image_stats_kernel(const float *__restric
 {
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
     float s0 = 0.f, s1 = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 a = reinterpret_cast<const float4 *>(image)[i], w = reinterpret_cast<const float4 *>(weight)[i];
+    const float4 *im4 = reinterpret_cast<const float4 *>(image), *w4 = reinterpret_cast<const float4 *>(weight);
+    auto term = [&](const float4 &a, const float4 &w) {
         s0 += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
         const float dx = a.x - mid, dy = a.y - mid, dz = a.z - mid, dw = a.w - mid;
         s1 += dx * dx + dy * dy + dz * dz + dw * dw;
+    };
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {   // eight 16-byte loads in flight per thread: a 6-iteration loop of dependent loads ran at 1 TB/s
+        const float4 a0 = im4[i], a1 = im4[i + stride], a2 = im4[i + 2 * stride], a3 = im4[i + 3 * stride];
+        const float4 b0 = w4[i], b1 = w4[i + stride], b2 = w4[i + 2 * stride], b3 = w4[i + 3 * stride];
+        term(a0, b0); term(a1, b1); term(a2, b2); term(a3, b3);
     }
+    for (; i < n4; i += stride) term(im4[i], w4[i]);
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail elements
         const size_t i = n4 * 4 + threadIdx.x;
         s0 += image[i] * weight[i];
@@ -55,7 +62,7 @@ extern "C" int ed3dgs_image_stats(const float *image, const float *weight, size_
 {
     if (!image || !weight || !acc || !out3 || n == 0) { set_error("ed3dgs_image_stats: null pointer or empty image"); return ED3DGS_ERR_INVALID; }
     if (((uintptr_t)image | (uintptr_t)weight) & 15) { set_error("ed3dgs_image_stats: image / weight must be 16-byte aligned"); return ED3DGS_ERR_INVALID; }
-    const int blocks = (int)std::min<size_t>(1024, (n / 4 + 255) / 256 + 1);
+    const int blocks = (int)std::min<size_t>(2048, (n / 4 + 1023) / 1024 + 1);
     hipLaunchKernelGGL(image_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, weight, n, mid, acc, out3);
     return check_hip(hipGetLastError(), "image_stats") ? 0 : ED3DGS_ERR_HIP;
 }
