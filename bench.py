@@ -235,7 +235,13 @@ def launch_ranks(a, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     log("launching %d ranks: %s" % (a.gpus, " ".join(cmd)))
-    return subprocess.run(cmd, env=env).returncode
+    # rank 0's JSON line goes to stdout; whatever else the ranks' libraries print there (gloo announces its connections on
+    # stdout) is passed on to stderr, so that the parent's stdout is the ONE line the contract asks for
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def hbm_ceiling(device, nbytes=1 << 30, reps=10):
