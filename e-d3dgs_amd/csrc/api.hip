@@ -4,6 +4,7 @@
 // legacy null stream throughout).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -155,18 +156,29 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!check_hip(hipMemcpyAsync(rb.host, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
-    if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
+    // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5
+    const size_t tr_bytes = getenv("ED3DGS_BIN_RADIX") ? 0 : bin_transpose_bytes(P, (int)T);
+    if (!tr_bytes) {
+        if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
+        if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
+    }
     if (!ok("depth order")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
     const uint32_t num_rendered_u = *rb.host;
     if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
     const int R = (int)num_rendered_u;
 
-    char *bin_chunk = binning_alloc(binning_user, ed3dgs_binning_bytes(R));
+    // (the transpose's counters ride at the END of the binning buffer: the backward carves the same layout from R alone)
+    char *bin_chunk = binning_alloc(binning_user, ed3dgs_binning_bytes(R) + tr_bytes);
     if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
-    bin = BinningState::from_chunk(bin_chunk, R);
+    char *bin_end = bin_chunk;
+    bin = BinningState::from_chunk(bin_end, R);
 
+    if (tr_bytes) {
+        launch_bin_transpose(P, width, height, geom, radii, bin_end, img.ranges, img.tile_order, bin.tile_keys, bin.point_list, s);
+        if (!ok("binTranspose")) return ED3DGS_ERR_HIP;
+        return R;
+    }
     launch_duplicate_with_keys(P, geom, radii, width, height, bin.tile_keys_unsorted, bin.point_list_unsorted, s);
     if (!ok("duplicateWithKeys")) return ED3DGS_ERR_HIP;
     const int bit = (int)higher_msb((uint32_t)T);
@@ -472,7 +484,7 @@ int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geome
         BinningState b = BinningState::from_chunk(bc, R);
         // the product path sorts 32-bit tile keys (binning.hip); the reference's 64-bit keys are composed here, for the
         // parity tests, from the sorted tile ids and the depths of the listed Gaussians
-        launch_compose_keys(R, b.tile_keys, b.point_list, g.depths, b.keys, nullptr);
+        launch_compose_keys((int)tiles_of(width, height), img.ranges, b.point_list, g.depths, b.keys, nullptr);
         if (!check_hip(hipGetLastError(), "compose keys") || !check_hip(hipDeviceSynchronize(), "compose keys sync")) return ED3DGS_ERR_HIP;
         out->point_list_keys = b.keys; out->point_list = b.point_list;
     }

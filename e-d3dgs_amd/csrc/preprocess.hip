@@ -307,6 +307,200 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Binning level 2 as a STABLE TRANSPOSE (round 2; replaces K3 + the level-2 radix sort + K5 + the tile-order sort when the
+// tile counters fit in LDS).  After level 1 the Gaussians are in depth order; a tile's list is the sub-sequence of that order
+// whose rects cover the tile -- the transpose of the (Gaussian in depth order) x (tile) incidence matrix, row order kept.
+// Rows are cut into blocks of 256 consecutive ranks:
+//   bin_count_kernel    block b counts its rows' instances per tile in LDS            -> C[b][t]
+//   bin_colscan_kernel  per tile: exclusive scan of C[.][t] over the blocks (in place) -> where block b's instances of tile t
+//                       start inside the tile's list, and the tile's total
+//   bin_tiles_kernel    one block: exclusive scan of the totals -> ranges (untouched tiles stay (0, 0), as K5 leaves them),
+//                       and the tile order of the tile kernels (longest list first)
+//   bin_scatter_kernel  block b (one wave) walks its 256 rows IN ORDER; a row's tiles are distinct, so lane = tile of the row:
+//                       position = the tile's cursor in LDS, cursor + 1 -- rows of a block stay in depth order inside every
+//                       tile, blocks are ordered by the column scan: the permutation is the stable sort's, ties included.
+// 4 launches and ~25 MB of counter traffic at 200k / 1080p instead of 19 launches (two 8-byte-pair radix passes over 3.3 M
+// instances with their histogram / look-back memsets, a scan, a memset, K3, K5, the order sort).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BIN_ROWS = 256;
+
+__global__ void __launch_bounds__(256) bin_count_kernel(int P, int T, const float *__restrict__ rec, const uint32_t *__restrict__ order,
+                                                        const int *__restrict__ radii, int gx, int gy, uint32_t *__restrict__ C)
+{
+    extern __shared__ uint32_t bin_lds[];
+    for (int t = threadIdx.x; t < T; t += 256) bin_lds[t] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * BIN_ROWS + threadIdx.x;
+    if (i < P) {
+        const uint32_t idx = order[i];
+        const int rad = radii[idx];
+        if (rad > 0) {
+            const float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
+            int2 rmin, rmax;
+            get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
+            for (int y = rmin.y; y < rmax.y; y++)
+                for (int x = rmin.x; x < rmax.x; x++) atomicAdd(&bin_lds[y * gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *row = C + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += 256) row[t] = bin_lds[t];
+}
+
+__global__ void __launch_bounds__(64) bin_colscan_kernel(int B, int T, uint32_t *__restrict__ C, uint32_t *__restrict__ total)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t run = 0;
+    int b = 0;
+    for (; b + 32 <= B; b += 32) {   // 32 loads in flight: the chain over the blocks is the tile's only dependency, and T threads are few
+        uint32_t c[32];
+#pragma unroll
+        for (int q = 0; q < 32; q++) c[q] = C[(size_t)(b + q) * T + t];
+#pragma unroll
+        for (int q = 0; q < 32; q++) { C[(size_t)(b + q) * T + t] = run; run += c[q]; }
+    }
+    for (; b < B; b++) { const uint32_t c = C[(size_t)b * T + t]; C[(size_t)b * T + t] = run; run += c; }
+    total[t] = run;
+}
+
+// one block: ranges = exclusive scan of the tile totals; tile order = counting sort of the tile ids by list length, longest first
+__global__ void __launch_bounds__(1024) bin_tiles_kernel(int T, const uint32_t *__restrict__ total, uint2 *__restrict__ ranges,
+                                                         uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t part[32], hist[256], cursor[256];
+    const int tid = threadIdx.x;
+    uint32_t run_base = 0;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    // slices of 8192 tiles (8 consecutive tiles per thread, loaded together: the LDS atomics below would otherwise order the loads)
+    for (int s0 = 0; s0 < T; s0 += 8192) {
+        const int t0 = s0 + tid * 8;
+        uint32_t n[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { n[q] = (t0 + q < T) ? total[t0 + q] : 0u; sum += n[q]; }
+        uint32_t inc0 = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = __shfl_up(inc0, o); if ((tid & 63) >= o) inc0 += nb; }
+        __syncthreads();                                       // part[] of the previous slice is no longer read
+        if ((tid & 63) == 63) part[tid >> 6] = inc0;           // wave totals
+        __syncthreads();
+        if (tid < 16) {
+            uint32_t w = part[tid], winc = w;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const uint32_t nb = __shfl_up(winc, o); if (tid >= o) winc += nb; }
+            part[16 + tid] = winc - w;                         // exclusive offset of wave tid
+            if (tid == 15) part[15] = winc;                    // the slice's total (part[15] as a wave total was read above)
+        }
+        __syncthreads();
+        uint32_t run = run_base + part[16 + (tid >> 6)] + inc0 - sum;
+        run_base += part[15];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (t0 + q < T) {
+                ranges[t0 + q] = n[q] ? make_uint2(run, run + n[q]) : make_uint2(0u, 0u);   // CR/rasterizer_impl.cu:388-395: untouched tiles stay (0, 0)
+                run += n[q];
+                atomicAdd(&hist[255 - min(255u, n[q] >> 3)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t v[4], s4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = hist[4 * tid + i]; s4 += v[i]; }
+        uint32_t inc = s4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = __shfl_up(inc, o); if (tid >= o) inc += nb; }
+        uint32_t base = inc - s4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cursor[4 * tid + i] = base; base += v[i]; }
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < T; s0 += 8192) {
+        const int t0 = s0 + tid * 8;
+        uint32_t n[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) n[q] = (t0 + q < T) ? total[t0 + q] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (t0 + q < T) order[atomicAdd(&cursor[255 - min(255u, n[q] >> 3)], 1u)] = (uint32_t)(t0 + q);
+    }
+}
+
+__global__ void __launch_bounds__(256) bin_scatter_kernel(int P, int T, const float *__restrict__ rec, const uint32_t *__restrict__ order,
+                                                         const int *__restrict__ radii, int gx, int gy, const uint32_t *__restrict__ C,
+                                                         const uint2 *__restrict__ ranges, uint32_t *__restrict__ tile_keys,
+                                                         uint32_t *__restrict__ point_list)
+{
+    extern __shared__ uint32_t bin_lds[];   // the tiles' cursors: where this block's next instance of tile t goes
+    // four waves: all walk the block's rows in order, wave w places the instances of the tiles t with (t & 3) == w -- a tile's
+    // instances stay in one wave, so their order is the rows' (one wave's LDS atomics complete in order)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t *row = C + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += 256) bin_lds[t] = ranges[t].x + row[t];
+    __syncthreads();
+    for (int i0 = 0; i0 < BIN_ROWS; i0 += 64) {
+        // 64 rows' data, one per lane; then the rows one after the other, the wave's lanes on the row's tiles
+        const int i = blockIdx.x * BIN_ROWS + i0 + lane;
+        uint32_t idx = 0;
+        int x0 = 0, y0 = 0, w = 0, n = 0;
+        if (i < P) {
+            idx = order[i];
+            const int rad = radii[idx];
+            if (rad > 0) {
+                const float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
+                int2 rmin, rmax;
+                get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
+                x0 = rmin.x; y0 = rmin.y; w = rmax.x - rmin.x; n = w * (rmax.y - rmin.y);
+            }
+        }
+        unsigned long long live = __ballot(n > 0);
+        // four rows at a time: their LDS atomics go out back to back (one wave's LDS operations complete in order, so two rows
+        // that share a tile still get consecutive positions in row order) and the stores follow
+        while (live) {
+            uint32_t ridx[4], tile[4], pos[4];
+            bool act[4];
+            int big = -1;                       // a rect of more than 64 tiles ends the group: it runs after the rows before it
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                act[q] = false; tile[q] = 0; ridx[q] = 0;
+                if (live && big < 0) {
+                    const int j = __builtin_ctzll(live);
+                    live &= live - 1;
+                    const int rn = __builtin_amdgcn_readlane(n, j);
+                    if (rn > 64) { big = j; continue; }
+                    ridx[q] = (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
+                    const int rx0 = __builtin_amdgcn_readlane(x0, j), ry0 = __builtin_amdgcn_readlane(y0, j);
+                    const int rw = __builtin_amdgcn_readlane(w, j);
+                    // lane = position inside the rect, row-major as K3 emits; small exact division in floating point
+                    const int ty = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)rw)), tx = lane - ty * rw;
+                    tile[q] = (uint32_t)((ry0 + ty) * gx + rx0 + tx);
+                    act[q] = lane < rn && (int)(tile[q] & 3u) == wv;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) pos[q] = act[q] ? atomicAdd(&bin_lds[tile[q]], 1u) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (act[q]) point_list[pos[q]] = ridx[q];
+            if (big >= 0) {
+                const uint32_t bidx = (uint32_t)__builtin_amdgcn_readlane((int)idx, big);
+                const int rx0 = __builtin_amdgcn_readlane(x0, big), ry0 = __builtin_amdgcn_readlane(y0, big);
+                const int rw = __builtin_amdgcn_readlane(w, big), rn = __builtin_amdgcn_readlane(n, big);
+                for (int e = lane; e < rn; e += 64) {
+                    const int ty = e / rw, tx = e - ty * rw;
+                    const uint32_t tl = (uint32_t)((ry0 + ty) * gx + rx0 + tx);
+                    if ((int)(tl & 3u) != wv) continue;
+                    const uint32_t ps = atomicAdd(&bin_lds[tl], 1u);
+                    point_list[ps] = bidx;
+                }
+            }
+        }
+    }
+}
+
 // K5: CR/rasterizer_impl.cu:151-173
 __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint32_t *__restrict__ tile_keys,
                                                                    uint32_t *__restrict__ ranges)
@@ -357,13 +551,14 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2 *__
 }
 
 // the reference's 64-bit sort keys, for the parity tests' state view only
-__global__ void __launch_bounds__(256) compose_keys_kernel(int L, const uint32_t *__restrict__ tile_keys,
+__global__ void __launch_bounds__(256) compose_keys_kernel(int T, const uint2 *__restrict__ ranges,
                                                            const uint32_t *__restrict__ point_list,
                                                            const float *__restrict__ depths, uint64_t *__restrict__ keys)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= L) return;
-    keys[idx] = ((uint64_t)tile_keys[idx] << 32) | (uint64_t)__float_as_uint(depths[point_list[idx]]);
+    const int t = blockIdx.x;   // one block per tile: the tile id of an instance is the tile whose range holds it
+    const uint2 r = ranges[t];
+    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += blockDim.x)
+        keys[i] = ((uint64_t)t << 32) | (uint64_t)__float_as_uint(depths[point_list[i]]);
 }
 
 void launch_preprocess(int P, int D, int M, const float *means, const float *scales, float scale_modifier,
@@ -405,17 +600,36 @@ void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ran
     hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, ranges);
 }
 
+size_t bin_transpose_bytes(int P, int T)   // the C matrix + the tile totals, or 0 when the tile counters do not fit in LDS
+{
+    if ((size_t)T * sizeof(uint32_t) > 48 * 1024 || P <= 0) return 0;
+    return ((size_t)((P + BIN_ROWS - 1) / BIN_ROWS) * T + (size_t)T) * sizeof(uint32_t) + 256;
+}
+
+void launch_bin_transpose(int P, int W, int H, const GeometryState &g, const int *radii, char *scratch, uint32_t *ranges,
+                          uint32_t *tile_order, uint32_t *tile_keys, uint32_t *point_list, hipStream_t s)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy, B = (P + BIN_ROWS - 1) / BIN_ROWS;
+    uint32_t *C = reinterpret_cast<uint32_t *>(((uintptr_t)scratch + 127) & ~(uintptr_t)127), *total = C + (size_t)B * T;
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(256), lds, s, P, T, g.rec, g.order, radii, gx, gy, C);
+    hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64), 0, s, B, T, C, total);   // one wave per block: 128 CUs busy instead of 32
+    hipLaunchKernelGGL(bin_tiles_kernel, dim3(1), dim3(1024), 0, s, T, total, reinterpret_cast<uint2 *>(ranges), tile_order);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(256), lds, s, P, T, g.rec, g.order, radii, gx, gy, C,
+                       reinterpret_cast<const uint2 *>(ranges), tile_keys, point_list);
+}
+
 void launch_tile_order(int T, const uint32_t *ranges, uint32_t *tile_order, hipStream_t s)
 {
     if (T <= 0) return;
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, T, reinterpret_cast<const uint2 *>(ranges), tile_order);
 }
 
-void launch_compose_keys(int R, const uint32_t *tile_keys, const uint32_t *point_list, const float *depths,
+void launch_compose_keys(int T, const uint32_t *ranges, const uint32_t *point_list, const float *depths,
                          uint64_t *keys, hipStream_t s)
 {
-    if (R <= 0) return;
-    hipLaunchKernelGGL(compose_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, point_list, depths, keys);
+    if (T <= 0) return;
+    hipLaunchKernelGGL(compose_keys_kernel, dim3(T), dim3(256), 0, s, T, reinterpret_cast<const uint2 *>(ranges), point_list, depths, keys);
 }
 
 }  // namespace ed3
