@@ -3189,9 +3189,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int LDG = WIDE ? 49 : 5;               // g_y slab row stride (odd); the last column stays zero
     constexpr int NG = WIDE ? 6 : 1;                 // g_y elements staged per thread and slab
     constexpr int KW3 = WIDE ? 24 : 2;               // k-steps of g_y . W3 on the f32 32x32x2 MFMA (two head outputs per step)
+    // narrow heads: the a slab goes global -> registers -> split -> piece image (4 x 16 bytes per thread, loaded one slab ahead):
+    // half the LDS-DMA pieces to issue (their issue is the largest non-MFMA item of a slab) and no staging round trip through
+    // LDS.  The wide head has no 16 registers to spare and keeps the LDS-DMA staging buffer.
+    constexpr bool AREG = !WIDE;
     __shared__ float zbuf0[SLAB];
     __shared__ float zbuf1[SLAB];
-    __shared__ float astage[SLAB];
+    __shared__ float astage[AREG ? 4 : SLAB];
     __shared__ __attribute__((aligned(256))) char aimg[24576];   // piece image of the a slab
     __shared__ float gs[32 * LDG];
     int jb = 0;
@@ -3253,6 +3257,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                                              (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
         }
     };
+    f32x4 areg[4];
+    auto load_a = [&](int slab) {   // the thread's four chunks of the split pass: (Gaussian idx >> 5, features 4 (idx & 31) ..), idx = tid + 256 i
+        const int r0 = p0 + slab * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + 256 * i, g = idx >> 5, cc = idx & 31;
+            areg[i] = *reinterpret_cast<const f32x4 *>(J.A + (size_t)min(r0 + g, p1 - 1) * HJ_W + cc * 4);
+        }
+    };
     auto load_g = [&](int slab) {
         const int r0 = p0 + slab * 32;
 #pragma unroll
@@ -3292,7 +3305,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #define WG_MARK(i_) do { if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tph[i_] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
     if (timed) tlast = clock64();
     dma_slab(J.ZR, zbuf0, 0);
-    dma_slab(J.A, astage, 0);
+    if constexpr (AREG) load_a(0); else dma_slab(J.A, astage, 0);
     load_g(0);
     auto body = [&](auto bufc, int slab) {
         constexpr int BUF = decltype(bufc)::value;
@@ -3305,7 +3318,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int idx = tid + 256 * i, g = idx >> 5, cc = idx & 31;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(astage + g * HJ_W + cc * 4);
+            f32x4 v;
+            if constexpr (AREG) v = areg[i]; else v = *reinterpret_cast<const f32x4 *>(astage + g * HJ_W + cc * 4);
             float r1[4], r2[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -3322,7 +3336,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         WG_MARK(1);
         __syncthreads();                                   // image and g_y slab ready; the staging buffer is free again
         WG_MARK(2);
-        if (slab + 1 < nslab && !(a.ablate & 1)) { dma_slab(J.ZR, BUF ? zbuf0 : zbuf1, slab + 1); dma_slab(J.A, astage, slab + 1); load_g(slab + 1); }
+        if (slab + 1 < nslab && !(a.ablate & 1)) {
+            dma_slab(J.ZR, BUF ? zbuf0 : zbuf1, slab + 1);
+            if constexpr (AREG) load_a(slab + 1); else dma_slab(J.A, astage, slab + 1);
+            load_g(slab + 1);
+        }
         WG_MARK(3);
 
         // g_z tile of this wave (Gaussian on the register index), masked by relu(z) > 0
