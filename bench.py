@@ -312,6 +312,10 @@ def main():
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, env_world))
         return rehearse(a, D)
     from ed3dgs_amd import _lib
+    # the rank's device is chosen BEFORE the process group exists: RCCL binds a rank to the device that is current when its
+    # communicator is created (first collective), and `barrier()` must not run on device 0 for every rank
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     rank, world, local = D.init()
     if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the torchrun environment has WORLD_SIZE=%d -- refusing to report a line "

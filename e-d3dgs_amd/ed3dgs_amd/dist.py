@@ -89,7 +89,10 @@ def allreduce_stats(loss_sum, psnr_sum, count, device):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":   # RCCL: on the rank's own device (the caller selected it before init())
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device):
