@@ -3684,12 +3684,12 @@ __global__ void __launch_bounds__(256) deform_dw1_kernel(Dw1Args a)
 }
 
 struct ZeroArgs {
-    float *p[4];
-    size_t n[4];
+    float *p[5];
+    size_t n[5];
 };
 __device__ __forceinline__ void deform_zero_kernel_body(const ZeroArgs &a, const int bx, const int by, const int nbx)
 {
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < 5; q++)
         for (size_t i = (size_t)bx * blockDim.x + threadIdx.x; i < a.n[q]; i += (size_t)nbx * blockDim.x) a.p[q][i] = 0.f;
 }
 __global__ void __launch_bounds__(256) deform_zero_kernel(ZeroArgs a) { deform_zero_kernel_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
@@ -4067,6 +4067,21 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     za.p[0] = g_table; za.n[0] = (size_t)cfg->max_embeddings * cfg->TD;
     za.p[1] = g_offsets; za.n[1] = (size_t)cfg->num_offsets;
     for (int st = 0; st < 2; st++) { za.p[2 + st] = cfg->use_stage[st] ? gparams[st] : nullptr; za.n[2 + st] = cfg->use_stage[st] ? pl.total : 0; }
+    za.p[4] = nullptr; za.n[4] = 0;
+    bool tail_zeroed = false;
+    {   // the kept data gradient's tail units add into dL/d embedding rows that must start from zero (see below): zeroed here too
+        const int NTc = cfg->W / 32;
+        const bool piped_c = NTc <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+        if (piped_c && activations_kept && cfg->P > 0 && g_embedding) {
+            const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
+            const int full_rounds = n_bi / G, rem_units = n_bi % G;
+            if (rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && rem_units * 2 <= G && !getenv("ED3DGS_DEFORM_NO_TAIL")) {
+                const size_t r0 = (size_t)full_rounds * G * 128;
+                za.p[4] = g_embedding + r0 * cfg->E; za.n[4] = ((size_t)cfg->P - r0) * cfg->E;
+                tail_zeroed = true;
+            }
+        }
+    }
     if (cfg->P == 0) {
         hipLaunchKernelGGL(deform_zero_kernel, dim3(256), dim3(256), 0, s, za);
         if (!check_hip(hipGetLastError(), "zero gradients")) return ED3DGS_ERR_HIP;
@@ -4134,7 +4149,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                     d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
                     d.tail_split = (d.rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && d.rem_units * 2 <= G &&
                                     !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
-                    if (d.tail_split) {   // the tail groups' rows of dL/d embedding are accumulated by two units each
+                    if (d.tail_split && !tail_zeroed) {   // the tail groups' rows of dL/d embedding are accumulated by two units each
                         const size_t r0 = (size_t)d.full_rounds * G * 128;
                         okp = check_hip(hipMemsetAsync(g_embedding + r0 * cfg->E, 0, ((size_t)cfg->P - r0) * cfg->E * sizeof(float), s), "memset g_emb tail");
                         if (!okp) return;

@@ -16,6 +16,7 @@ Q1_REFERENCE = True
 # bench.py / tests: when KEEP_LAST is set, the most recent forward's (num_rendered, H, W, state buffers) stay reachable
 KEEP_LAST = False
 LAST = {}
+_ZERO = {}   # device -> the 0-d zero behind the planes a variant does not produce
 
 
 def _ptr(t):
@@ -84,8 +85,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scal
             return torch.empty((c, H, W), **fopt)
         if run:
             # a plane the variant does not produce (the reference returns freshly filled zeros: 25 MB and a launch each at
-            # 1080p): one zero expanded to the shape.  Reads as zeros everywhere; an in-place write raises instead of aliasing.
-            return torch.zeros((), **fopt).expand(c, H, W)
+            # 1080p): one zero (per device, made once) expanded to the shape.  Reads as zeros everywhere; an in-place write raises
+            # instead of aliasing.
+            z = _ZERO.get(dev)
+            if z is None:
+                z = _ZERO[dev] = torch.zeros((), **fopt)
+            return z.expand(c, H, W)
         return torch.zeros((c, H, W), **fopt)
     out_color = mk(NUM_CHANNELS, True)
     out_depth, out_mdepth = mk(1, rd), mk(1, rd)
