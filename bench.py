@@ -489,8 +489,8 @@ def main():
         2: ({"exact_split": "deform_forward_b3_kernel<4,3>", "bf16x3": "deform_forward_b3_kernel<4,2>", "fp32_mfma": "deform_forward_pipe_kernel<4>"}[mode], mac_all, npr),
         3: ({"exact_split": "deform_dgrad_kept_bn_kernel<4,3>", "bf16x3": "deform_dgrad_kept_b3_kernel<4>", "fp32_mfma": "deform_dgrad_kept_kernel<4>"}[mode], mac_all, npr),
         5: ("deform_dw1_kernel", mac_trunk, 1),
-        6: ({"exact_split": "deform_head_wgrad_kernel<true,false,true>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false,true>"}[mode], mac_wide, 3 if mode == "bf16x3" else 1),
-        7: ({"exact_split": "deform_head_wgrad_narrow_bn_kernel<3>", "bf16x3": "deform_head_wgrad_kernel<false,true,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false,true>"}[mode], mac_narrow, npr),
+        6: ({"exact_split": "deform_head_wgrad_tr_kernel<true>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false,true>"}[mode], mac_wide, {"exact_split": 8, "bf16x3": 3, "fp32_mfma": 1}[mode]),
+        7: ({"exact_split": "deform_head_wgrad_tr_kernel<false>", "bf16x3": "deform_head_wgrad_kernel<false,true,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false,true>"}[mode], mac_narrow, npr),
     }
     tfl = lambda mac, ms: 2.0 * mac * wl["P"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kernels = {
@@ -565,8 +565,8 @@ def main():
     }
     res["deform_mode"] = {"mode": mode, "note": {
         "exact_split": "default: fp32 operands split exactly into three bf16 pieces; the eight piece products above 2^-32 "
-                       "accumulate in fp32 on the bf16 MFMA (forward, kept data gradient, narrow-head weight gradients; wide head "
-                       "and dW1 on the f32 MFMA).  Results at the f32-MFMA kernels' error level (tests/test_deform_parity_gpu.py)",
+                       "accumulate in fp32 on the bf16 MFMA (forward, kept data gradient, head weight gradients; the small g_y . W3 "
+                       "products and dW1 on the f32 MFMA).  Results at the f32-MFMA kernels' error level (tests/test_deform_parity_gpu.py)",
         "fp32_mfma": "every contraction on the f32-operand MFMA", "bf16x3": "REDUCED precision (two pieces, three products)"}[mode]}
     if f32m is not None:
         res["fp32_mfma_mode"] = f32m
