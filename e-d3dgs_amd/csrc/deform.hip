@@ -102,6 +102,10 @@ struct DeformDev {
     int full_rounds, rem_units, tail_split;  // forward block schedule (see deform_forward_pipe_kernel)
     int keep;      // forward writes a = relu(hid) and relu(z_k) for the backward (activations kept instead of re-formed)
     int store_gz;  // dgrad writes g_z (only the generic wgrad path reads it back)
+    // backward over the ACTIVE rows only (see deform_active_rows_body): rows[0 .. *n_act) are the Gaussians with a non-zero
+    // upstream gradient; NULL = every Gaussian.  g_hid is then written compactly (row i of GHID = Gaussian rows[i]).
+    const int *rows, *n_act;
+    int no_tail;
     int ablate;  // diagnostic builds only: bit mask of phases to skip (timing experiments; results are then wrong)
     unsigned long long *timing;  // diagnostic (ED3DGS_FWD_TIMING): per-phase cycle sums of block 0's waves in the narrow-head tile loop
 };
@@ -2001,24 +2005,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // are independent up to dL/d embedding, which the two units add atomically into zeroed rows (two addends: the
     // result does not depend on their order)
     const int b = (int)blockIdx.x, G = (int)gridDim.x;
-    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
-    const bool has_tail = d.tail_split && b < d.rem_units * 2;
+    // rows to walk: all P, or the active list (its length is known on the device only: the schedule is then formed here)
+    int n_rows = d.P, full_rounds = d.full_rounds, rem_units = d.rem_units, tail_split = d.tail_split;
+    if (d.rows) {
+        n_rows = __builtin_amdgcn_readfirstlane(*d.n_act);
+        if (n_rows <= 0) return;
+        const int nb = (n_rows + 127) / 128;
+        full_rounds = nb / G; rem_units = nb - full_rounds * G;
+        tail_split = (rem_units > 0 && both && rem_units * 2 <= G && !d.no_tail) ? 1 : 0;
+    }
+    const int my_full = full_rounds + ((!tail_split && b < rem_units) ? 1 : 0);
+    const bool has_tail = tail_split && b < rem_units * 2;
     const int tail_s = has_tail ? (b & 1) : -1;
-    const int tail_bi = d.full_rounds * G + (b >> 1);
+    const int tail_bi = full_rounds * G + (b >> 1);
     (void)n_bi;
     const size_t PW = (size_t)d.P * d.W;
     constexpr int PIPE_CHF = (((NT) + OTMAX) * TS + 1023) & ~1023;
     constexpr int PIPE_NI = PIPE_CHF / 1024;
     ChunkSeqKept<NT, TS> pipe_seq;
     int pipe_n = 0, pipe_total = 0;
+    if (my_full + (has_tail ? 1 : 0) == 0) return;
     GPIPE_START_SPREAD(my_full * per_iter + (has_tail ? n_en * NT + 1 : 0), my_full, tail_s);
     for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
         const int bi = (it < my_full) ? b + it * G : tail_bi;
         const int sonly = (it < my_full) ? -1 : tail_s;
-        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
-        const bool gvalid = g_raw < d.P;
-        const bool wave_valid = bi * 128 + wave * 32 < d.P;   // wave-uniform: the wave's g_hid stores are issued
-        const int g = gvalid ? g_raw : d.P - 1;
+        const int i_raw = bi * 128 + wave * 32 + (lane & 31);   // position in the walk; g_hid row
+        const bool gvalid = i_raw < n_rows;
+        const bool wave_valid = bi * 128 + wave * 32 < n_rows;   // wave-uniform: the wave's g_hid stores are issued
+        const int i_row = gvalid ? i_raw : n_rows - 1;
+        const int g = d.rows ? d.rows[i_row] : i_row;
         f32x16 ge;
 #pragma unroll
         for (int r = 0; r < 16; r++) ge[r] = 0.f;
@@ -2120,7 +2135,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     float gh[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) gh[r] = (mka >> (16 * nt + r)) & 1ull ? ga[nt][r] : 0.f;
-                    if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh);
+                    if (gvalid) store_tile_rows(d.GHID[s], d.W, i_row, nt, h, gh);
                     XSplitN<NP> ghs;
                     split_tile_n<NP>(gh, ghs);
                     ge = gemm_tile_bn<NP>(PIPE_CUR() + nt * TS, ghs, ge, lane);
@@ -2671,6 +2686,7 @@ struct HeadJob {
 constexpr int MAXHEADJOBS = 2 * NHEAD;
 struct HeadWgradArgs {
     int P, njobs;
+    const int *rows, *n_act;      // active rows (NULL: all): slabs are 32 list entries, every per-Gaussian read is a gather
     unsigned long long *timing;   // diagnostic (ED3DGS_WG_TIMING): per-phase cycle sums of block 0's waves, [wave][8]
     int ablate;   // diagnostic (ED3DGS_WG_ABLATE; results are then wrong): 1 no DMA after the first slab, 2 no dW2 MFMAs, 4 no split pass
     int blk_begin[MAXHEADJOBS + 1];
@@ -3207,13 +3223,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ float astage[AREG ? 4 : SLAB];
     __shared__ __attribute__((aligned(256))) char aimg[24576];   // piece image of the a slab
     __shared__ float gs[32 * LDG];
+    __shared__ int rid0[32];                         // Gaussian ids of a slab's 32 rows (two slabs: one being fetched, one in use);
+    __shared__ int rid1[32];                         // separate objects, like the z buffers
     int jb = 0;
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
     const HeadJob &J = a.job[jb];
     const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = J.nk, P = a.P;
+    const int nk = J.nk, P = a.rows ? __builtin_amdgcn_readfirstlane(*a.n_act) : a.P;   // rows to walk
     const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
     const int p0 = split * chunk, p1 = min(P, p0 + chunk);
     if (p0 >= p1) return;
@@ -3239,64 +3257,61 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     f32x8 gv, g2v;
     const bool has_g2 = J.G2 != nullptr;
-    const int gcount = 32 * nk;
-    // db3 = sum over Gaussians of g_y: every thread sums the slab elements it stages (element e of a slab is head output
-    // e % nk in EVERY slab, since a slab holds 32 * nk elements) and adds its NG partial sums once, at the end
+    // g_y staging: thread (row tid >> 3, column slot tid & 7) holds head outputs (tid & 7) + 8 i, i < NG, of ONE Gaussian -- one
+    // row id and one address register per slab, the NG loads at immediate offsets.
+    // db3 = sum over Gaussians of g_y: a thread's register i is the same head output in every slab, so it sums what it stages
+    // and adds its NG partial sums once, at the end
     float bsum3[NG];
 #pragma unroll
     for (int i = 0; i < NG; i++) bsum3[i] = 0.f;
-    // ... and (row e / nk, column e % nk) likewise: LDS offsets computed once, two per register (a division by the runtime
-    // nk is ~40 instructions)
-    unsigned gpk[(NG + 1) / 2];
+    const int grow = tid >> 3, gcol = tid & 7;
+    // Gaussian id of row r of a slab: from the slab's id table (filled one slab ahead, see fetch_ids / put_ids).  This thread's
+    // four rows 8 i + 2 wave + h are the same for the z slab's DMA pieces, the a slab's, and the register form of the a slab:
+    // one 32-bit element offset each (P * 128 < 2^30 is checked on the host)
+    unsigned ro[4];
+    auto row_offsets = [&](const int *rid) {
 #pragma unroll
-    for (int i = 0; i < NG; i++) {
-        const int e = tid + 256 * i, r = min(e / nk, 31), cc = e - (e / nk) * nk;
-        const unsigned v = (unsigned)(r * LDG + cc) | ((unsigned)r << 11);          // offset < 2048, row in the high bits
-        if (i & 1) gpk[i >> 1] |= v << 16; else gpk[i >> 1] = v;
-    }
-
+        for (int i = 0; i < 4; i++) ro[i] = (unsigned)rid[8 * i + 2 * wave + h] * (unsigned)HJ_W + (unsigned)(c * 4);
+    };
     // 16 KB = 16 DMA instructions of 1 KB (2 rows), 4 per wave; rows past the range re-read the last row
-    auto dma_slab = [&](const float *src, float *dst, int slab) {
-        const int r0 = p0 + slab * 32;
+    auto dma_slab = [&](const float *src, float *dst) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int piece = i * 4 + wave, row = piece * 2 + h, col = c * 4;
-            const size_t o = (size_t)min(r0 + row, p1 - 1) * HJ_W + col;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+            const int piece = i * 4 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ro[i]),
                                              (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
         }
     };
     f32x4 areg[4];
-    auto load_a = [&](int slab) {   // the thread's four chunks of the split pass: (Gaussian idx >> 5, features 4 (idx & 31) ..), idx = tid + 256 i
-        const int r0 = p0 + slab * 32;
+    auto load_a = [&]() {   // the thread's four chunks of the split pass: (Gaussian idx >> 5, features 4 (idx & 31) ..), idx = tid + 256 i
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = tid + 256 * i, g = idx >> 5, cc = idx & 31;
-            areg[i] = *reinterpret_cast<const f32x4 *>(J.A + (size_t)min(r0 + g, p1 - 1) * HJ_W + cc * 4);
-        }
+        for (int i = 0; i < 4; i++) areg[i] = *reinterpret_cast<const f32x4 *>(J.A + ro[i]);
     };
-    auto load_g = [&](int slab) {
-        const int r0 = p0 + slab * 32;
+    auto load_g = [&](const int *rid) {
+        const unsigned o = (unsigned)rid[grow] * (unsigned)nk;   // 32-bit: one address register
 #pragma unroll
         for (int i = 0; i < NG; i++) {
-            const int e = tid + 256 * i;
-            const size_t o = (size_t)r0 * nk + min(e, (p1 - r0) * nk - 1);
-            gv[i] = J.G[o];
-            if (has_g2) g2v[i] = J.G2[o];
+            const unsigned cc = (unsigned)min(gcol + 8 * i, nk - 1);   // columns past nk: a re-read, not stored
+            gv[i] = J.G[o + cc];
+            if (has_g2) g2v[i] = J.G2[o + cc];
         }
+    };
+    // ids of the rows of slab `slab`: lane (tid & 31) fetches entry p0 + 32 slab + (tid & 31) of the list (clamped to the range:
+    // rows past it re-read the last row and are masked out); fetched one slab before put_ids publishes them
+    auto fetch_ids = [&](int slab) {
+        const int i = min(p0 + slab * 32 + c, p1 - 1);
+        return a.rows ? a.rows[i] : i;
     };
     auto store_g = [&](int slab) {
-        const int r0 = p0 + slab * 32;
+        const bool live = p0 + slab * 32 + grow < p1;                    // rows past the range contribute nothing
 #pragma unroll
         for (int i = 0; i < NG; i++) {
-            const int e = tid + 256 * i;
-            if (e < gcount) {
-                const unsigned pk = (gpk[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                const int r = (int)(pk >> 11), off = (int)(pk & 0x7FFu);
+            const int cc = gcol + 8 * i;
+            if (cc < nk) {
                 float v = gv[i];
                 if (has_g2) v += g2v[i];
-                v = (r0 + r < p1) ? v * J.gscale : 0.f;                  // rows past the range contribute nothing
-                gs[off] = v;
+                v = live ? v * J.gscale : 0.f;
+                gs[grow * LDG + cc] = v;
                 bsum3[i] += v;
             }
         }
@@ -3313,14 +3328,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const bool timed = a.timing != nullptr && blockIdx.x == 0;
 #define WG_MARK(i_) do { if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tph[i_] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
     if (timed) tlast = clock64();
-    dma_slab(J.ZR, zbuf0, 0);
-    if constexpr (AREG) load_a(0); else dma_slab(J.A, astage, 0);
-    load_g(0);
+    int ids_next = fetch_ids(0);
+    if (tid < 32) rid0[tid] = ids_next;
+    __syncthreads();
+    row_offsets(rid0);
+    dma_slab(J.ZR, zbuf0);
+    if constexpr (AREG) load_a(); else dma_slab(J.A, astage);
+    load_g(rid0);
+    ids_next = fetch_ids(min(1, nslab - 1));
     auto body = [&](auto bufc, int slab) {
         constexpr int BUF = decltype(bufc)::value;
         const float *zs = BUF ? zbuf1 : zbuf0;
+        int *rid_nx = BUF ? rid0 : rid1;
         __syncthreads();                                   // slab's DMA landed; every wave is done with the previous slab
         WG_MARK(0);
+        if (tid < 32) rid_nx[tid] = ids_next;              // ids of slab + 1 (fetched during the previous slab)
         store_g(slab);
         // split pass: 1024 chunks of 4 features, 4 per thread; x = p0 + p1 + p2 exactly (see split8_n)
         if (!(a.ablate & 4))
@@ -3346,10 +3368,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();                                   // image and g_y slab ready; the staging buffer is free again
         WG_MARK(2);
         if (slab + 1 < nslab && !(a.ablate & 1)) {
-            dma_slab(J.ZR, BUF ? zbuf0 : zbuf1, slab + 1);
-            if constexpr (AREG) load_a(slab + 1); else dma_slab(J.A, astage, slab + 1);
-            load_g(slab + 1);
+            row_offsets(rid_nx);
+            dma_slab(J.ZR, BUF ? zbuf0 : zbuf1);
+            if constexpr (AREG) load_a(); else dma_slab(J.A, astage);
+            load_g(rid_nx);
         }
+        ids_next = fetch_ids(min(slab + 2, nslab - 1));
         WG_MARK(3);
 
         // g_z tile of this wave (Gaussian on the register index), masked by relu(z) > 0
@@ -3477,13 +3501,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (tid < 64) gs[tid] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NG; i++) {
-        const int e = tid + 256 * i;
-        if (e < gcount) {
-            const unsigned pk = (gpk[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            atomicAdd(&gs[(int)(pk & 0x7FFu) - (int)(pk >> 11) * LDG], bsum3[i]);
-        }
-    }
+    for (int i = 0; i < NG; i++)
+        if (gcol + 8 * i < nk) atomicAdd(&gs[gcol + 8 * i], bsum3[i]);
     __syncthreads();
     if (tid < nk) atomicAdd(J.db3 + tid, gs[tid]);
 }
@@ -3613,6 +3632,7 @@ struct Dw1Job {
 };
 struct Dw1Args {
     int P, njobs;
+    const int *rows, *n_act;   // active rows (NULL: all): G is compact (row i = Gaussian rows[i]), E is gathered
     int blk_begin[3];
     Dw1Job job[2];
 };
@@ -3626,12 +3646,18 @@ __global__ void __launch_bounds__(256) deform_dw1_kernel(Dw1Args a)
     const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = a.P;
+    const int P = a.rows ? __builtin_amdgcn_readfirstlane(*a.n_act) : a.P;   // rows to walk
     const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
     const int p0 = split * chunk, p1 = min(P, p0 + chunk);
     if (p0 >= p1) return;
     const int nslab = (p1 - p0 + 31) / 32;
-    auto dma = [&](int slab, int buf) {
+    // the embedding row this lane fetches of a slab (8 rows per 1 KB piece); with a row list its id is read one slab ahead
+    const int erow = wave * 8 + (lane >> 3);
+    auto row_id = [&](int slab) {
+        const int i = min(p0 + slab * 32 + erow, p1 - 1);
+        return a.rows ? a.rows[i] : i;
+    };
+    auto dma = [&](int slab, int buf, int eid) {
         const int r0 = p0 + slab * 32;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -3640,19 +3666,21 @@ __global__ void __launch_bounds__(256) deform_dw1_kernel(Dw1Args a)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.G + (size_t)min(r0 + row, p1 - 1) * 128 + col),
                                              (__attribute__((address_space(3))) void *)(hj_lds + buf * BUF + piece * 256), 16, 0, 0);
         }
-        const int row = wave * 8 + (lane >> 3), col = (lane & 7) * 4;   // 1 KB = 8 rows of the embedding
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.E + (size_t)min(r0 + row, p1 - 1) * 32 + col),
+        const int col = (lane & 7) * 4;                        // 1 KB = 8 rows of the embedding
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.E + (size_t)eid * 32 + col),
                                          (__attribute__((address_space(3))) void *)(hj_lds + buf * BUF + GS + wave * 256), 16, 0, 0);
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     float bsum = 0.f;
-    dma(0, 0);
+    dma(0, 0, row_id(0));
+    int eid_next = row_id(min(1, nslab - 1));
     __syncthreads();
     for (int slab = 0; slab < nslab; slab++) {
         const int buf = slab & 1;
-        if (slab + 1 < nslab) dma(slab + 1, buf ^ 1);
+        if (slab + 1 < nslab) dma(slab + 1, buf ^ 1, eid_next);
+        eid_next = row_id(min(slab + 2, nslab - 1));
         const float *gs = hj_lds + buf * BUF, *es = gs + GS;
         const int rows = min(32, p1 - (p0 + slab * 32));       // rows past the range hold a re-read row
 #pragma unroll
@@ -3683,6 +3711,94 @@ __global__ void __launch_bounds__(256) deform_dw1_kernel(Dw1Args a)
     if (h == 0) atomicAdd(J.db + wave * 32 + c, v);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Active rows of a backward.  A Gaussian that no pixel blended (outside the frustum, radius 0, or behind the last contributor
+// of every tile it touches: more than half of a dense scene in any one view) arrives with all-zero rows in every upstream
+// gradient, and the deformation backward's work for such a row -- its data gradient, its share of every weight gradient -- is
+// exactly zero.  One pass over the upstream tensors (it is the only pass that reads all of them) flags the rows with a
+// non-zero element, appends their indices to `rows` (a block's 256 Gaussians stay in order; blocks append in the order
+// they finish) and leaves the count in ctr[2]; the data-gradient and weight-gradient kernels then walk rows[0 .. n) instead of
+// 0 .. P.  Results are those of the dense backward: the skipped rows contribute exact zeros (dL/d embedding rows of the
+// skipped Gaussians are zeroed by the same launch).  The same pass writes dL/d(base SH) = g_sh + gs_sh in the caller's split
+// layout ([P,1,3] and [P,n_sh-1,3], the reference's _features_dc / _features_rest) when asked to, which saves the caller the
+// strided copies autograd would make of the two slices.
+// ctr[0] = append cursor, ctr[1] = finished-block ticket: both zero on entry (the forward that kept the activations zeroes
+// them) and re-armed by the last block, so that a second backward over the same workspace finds them zero again.
+// ------------------------------------------------------------------------------------------------------------
+struct ActiveArgs {
+    int P, nblk, shw, sh_in_flags;
+    const float *g[8];            // upstream tensors of the enabled narrow heads (dL/d out, dL/d sub), NULL = absent
+    int nk[8];
+    const float *sh_a, *sh_b;     // g_sh, gs_sh
+    float *sh_dc, *sh_rest;       // optional split output of g_sh + gs_sh
+    int *rows, *ctr;
+};
+__device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, const int bx)
+{
+    __shared__ int fl[256];
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g0 = bx * 256, nrow = min(256, a.P - g0);
+    fl[tid] = 0;
+    __syncthreads();
+    for (int q = 0; q < 8; q++) {
+        const float *p = a.g[q];
+        if (!p) continue;
+        const int nk = a.nk[q], n = nrow * nk;
+        p += (size_t)g0 * nk;
+        for (int e = tid; e < n; e += 256)
+            if (p[e] != 0.f) fl[e / nk] = 1;
+    }
+    if (a.sh_a || a.sh_b) {
+        const int c4 = a.shw >> 2, n = nrow * c4, rw = a.shw - 3;
+        for (int idx = tid; idx < n; idx += 256) {
+            const size_t o = (size_t)g0 * a.shw + (size_t)idx * 4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (a.sh_a) va = *reinterpret_cast<const float4 *>(a.sh_a + o);
+            if (a.sh_b) vb = *reinterpret_cast<const float4 *>(a.sh_b + o);
+            const int row = idx / c4, c = idx - row * c4;
+            const bool nz = va.x != 0.f || va.y != 0.f || va.z != 0.f || va.w != 0.f || vb.x != 0.f || vb.y != 0.f || vb.z != 0.f || vb.w != 0.f;
+            if (a.sh_in_flags && nz) fl[row] = 1;
+            if (a.sh_dc) {
+                const float4 v = a.sh_b ? make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w) : va;
+                const size_t gr = (size_t)(g0 + row);
+                if (c == 0) {
+                    float *d3 = a.sh_dc + gr * 3;
+                    d3[0] = v.x; d3[1] = v.y; d3[2] = v.z;
+                    a.sh_rest[gr * rw] = v.w;
+                } else {
+                    float *r4 = a.sh_rest + gr * rw + 4 * c - 3;
+                    r4[0] = v.x; r4[1] = v.y; r4[2] = v.z; r4[3] = v.w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool act = tid < nrow && fl[tid] != 0;
+    const unsigned long long bal = __ballot(act);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base_s = tot ? atomicAdd(&a.ctr[0], tot) : 0;
+    }
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (act) a.rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = g0 + tid;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int t = atomicAdd(&a.ctr[1], 1);
+        if (t == a.nblk - 1) {   // last block: publish the count, re-arm the counters
+            const int n = atomicAdd(&a.ctr[0], 0);
+            a.ctr[2] = n; a.ctr[0] = 0; a.ctr[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
 struct ZeroArgs {
     float *p[5];
     size_t n[5];
@@ -3702,7 +3818,8 @@ struct PrepArgs {
     FragArgs fa;
     FrameArgs fr;
     ZeroArgs za;
-    int nb[6];          // blocks of: fragments, chunks, b3 backward chunks, kept chunks, frame (2), zeroing
+    ActiveArgs aa;
+    int nb[7];          // blocks of: fragments, chunks, b3 backward chunks, kept chunks, frame (2), zeroing, active rows
     int chunk_pieces;   // 3 / 2: deform_chunk_b3_kernel<3 / 2>; 0: deform_chunk_kernel
 };
 __global__ void __launch_bounds__(256) deform_prep_kernel(PrepArgs p)
@@ -3724,7 +3841,9 @@ __global__ void __launch_bounds__(256) deform_prep_kernel(PrepArgs p)
     bx -= p.nb[3];
     if (bx < p.nb[4]) { if (by == 0) deform_frame_kernel_body(p.fr, bx, 0, p.nb[4]); return; }
     bx -= p.nb[4];
-    if (bx < p.nb[5] && by == 0) deform_zero_kernel_body(p.za, bx, 0, p.nb[5]);
+    if (bx < p.nb[5]) { if (by == 0) deform_zero_kernel_body(p.za, bx, 0, p.nb[5]); return; }
+    bx -= p.nb[5];
+    if (bx < p.nb[6] && by == 0) deform_active_rows_body(p.aa, bx);
 }
 
 struct FrameBwdArgs {
@@ -3843,6 +3962,7 @@ static bool can_keep(const ed3dgs_deform_cfg *c)
 struct Workspace {
     float *frag[2]; float *fs; float *A[2], *ZR[2], *GZ[2], *GHID[2];
     unsigned long long *MK[2];
+    int *rows, *ctr;   // active rows of the backward and their counters (deform_active_rows_body)
 };
 static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace *ws)
 {
@@ -3851,8 +3971,11 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
     Workspace w;
     for (int s = 0; s < 2; s++) obtain(p, w.frag[s], fl.total, 256);
     obtain(p, w.fs, 2 * FS_STRIDE, 256);
+    w.rows = w.ctr = nullptr;
     if (bwd) {
         const size_t PW = (size_t)(c->P > 0 ? c->P : 0) * c->W;
+        obtain(p, w.ctr, 64, 256);
+        obtain(p, w.rows, (size_t)(c->P > 0 ? c->P : 0) + 64, 256);
         for (int s = 0; s < 2; s++) {
             obtain(p, w.A[s], PW, 256); obtain(p, w.ZR[s], NHEAD * PW, 256);
             // g_z is stored only for the generic weight-gradient kernel; the head jobs re-form it on chip
@@ -3882,7 +4005,8 @@ static int fwd_pieces(const ed3dgs_deform_cfg *c)
 }
 
 static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float *offsets, const float *const params[2],
-                     const Workspace &w, bool bwd, hipStream_t s, bool kept = false, const ZeroArgs *zero = nullptr)
+                     const Workspace &w, bool bwd, hipStream_t s, bool kept = false, const ZeroArgs *zero = nullptr,
+                     const ActiveArgs *active = nullptr)
 {
     ParamLayout pl = param_layout(c->W, c->TD, c->E, c->n_sh);
     FragLayout fl = frag_layout(c->W, c->E, bwd);
@@ -3922,13 +4046,18 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     }
     if (pa.nb[3]) pa.nb[1] = 0;   // the kept builder writes the chunk region in its own format, all of it
     pa.nb[4] = 2;
-    pa.nb[5] = zero ? 256 : 0;
-    const int nb_total = pa.nb[0] + pa.nb[1] + pa.nb[2] + pa.nb[3] + pa.nb[4] + pa.nb[5];
+    if (zero) {
+        size_t nz = 0;
+        for (int q = 0; q < 5; q++) nz += zero->n[q];
+        pa.nb[5] = (int)std::max<size_t>(1, std::min<size_t>(256, (nz + 16383) / 16384));
+    }
+    if (active) { pa.aa = *active; pa.nb[6] = active->nblk; }
+    const int nb_total = pa.nb[0] + pa.nb[1] + pa.nb[2] + pa.nb[3] + pa.nb[4] + pa.nb[5] + pa.nb[6];
     if (getenv("ED3DGS_PREP_SEQ")) {   // diagnostic: the parts one launch at a time
-        for (int q = 0; q < 6; q++) {
+        for (int q = 0; q < 7; q++) {
             if (!pa.nb[q]) continue;
             PrepArgs one = pa;
-            for (int r = 0; r < 6; r++) if (r != q) one.nb[r] = 0;
+            for (int r = 0; r < 7; r++) if (r != q) one.nb[r] = 0;
             hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)one.nb[q], 2), dim3(256), 0, s, one);
         }
         return check_hip(hipGetLastError(), "deform prep");
@@ -3936,7 +4065,7 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     if (pa.nb[2]) {   // split-bf16 mode: its builder re-packs tiles of the fp32 chunks in place -> a launch of its own, after them
         PrepArgs first = pa, second = pa;
         first.nb[2] = 0;
-        for (int r = 0; r < 6; r++) if (r != 2) second.nb[r] = 0;
+        for (int r = 0; r < 7; r++) if (r != 2) second.nb[r] = 0;
         hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)(nb_total - pa.nb[2]), 2), dim3(256), 0, s, first);
         hipLaunchKernelGGL(deform_prep_kernel, dim3((unsigned)pa.nb[2], 2), dim3(256), 0, s, second);
         return check_hip(hipGetLastError(), "deform prep");
@@ -3989,7 +4118,10 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     carve(cfg, keep, workspace, &w);   // keep: the backward's carve, so that A / ZR sit where the backward reads them
-    if (!run_prep(cfg, table, offsets, params, w, false, s)) return ED3DGS_ERR_HIP;
+    ZeroArgs zf;
+    std::memset(&zf, 0, sizeof zf);
+    if (keep) { zf.p[0] = reinterpret_cast<float *>(w.ctr); zf.n[0] = 4; }   // the backward's active-row counters start from zero
+    if (!run_prep(cfg, table, offsets, params, w, false, s, false, keep ? &zf : nullptr)) return ED3DGS_ERR_HIP;
     DeformDev d;
     std::memset(&d, 0, sizeof d);
     fill_dev(cfg, d, false);
@@ -4069,7 +4201,15 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     for (int st = 0; st < 2; st++) { za.p[2 + st] = cfg->use_stage[st] ? gparams[st] : nullptr; za.n[2 + st] = cfg->use_stage[st] ? pl.total : 0; }
     za.p[4] = nullptr; za.n[4] = 0;
     bool tail_zeroed = false;
-    {   // the kept data gradient's tail units add into dL/d embedding rows that must start from zero (see below): zeroed here too
+    // the default configuration (kept activations, exact three-piece kernels) walks the active rows only
+    const bool compact = activations_kept && cfg->P > 0 && cfg->P < (1 << 23) && g_embedding && fwd_pieces(cfg) == 3 && cfg->W == HJ_W && cfg->E == 32 &&
+                         3 * cfg->n_sh <= 48 && !getenv("ED3DGS_DEFORM_WGRAD_R1") && !getenv("ED3DGS_DEFORM_DW1_GENERIC") &&
+                         !getenv("ED3DGS_DEFORM_GENERIC_WGRAD") && !getenv("ED3DGS_DEFORM_FUSED_BWD") && !getenv("ED3DGS_DEFORM_DENSE_BWD");
+    if (compact) {   // rows of skipped Gaussians (and the tail units' rows) of dL/d embedding start from zero
+        za.p[4] = g_embedding; za.n[4] = (size_t)cfg->P * cfg->E;
+        tail_zeroed = true;
+    }
+    if (!compact) {   // the kept data gradient's tail units add into dL/d embedding rows that must start from zero (see below): zeroed here too
         const int NTc = cfg->W / 32;
         const bool piped_c = NTc <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
         if (piped_c && activations_kept && cfg->P > 0 && g_embedding) {
@@ -4090,10 +4230,26 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     if (!embedding || !g_embedding) { set_error("ed3dgs_deform_backward: null embedding pointer"); return ED3DGS_ERR_INVALID; }
     Workspace w;
     carve(cfg, true, workspace, &w);
-    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0, &za)) return ED3DGS_ERR_HIP;
     DeformDev d;
     std::memset(&d, 0, sizeof d);
     fill_dev(cfg, d, true);
+    ActiveArgs aa;
+    std::memset(&aa, 0, sizeof aa);
+    if (compact) {
+        const float *gin[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
+        const float *gsin[5] = {gs_xyz, gs_scales, gs_rot, gs_opacity, gs_sh};
+        aa.P = cfg->P; aa.nblk = (cfg->P + 255) / 256; aa.shw = 3 * cfg->n_sh;
+        for (int k = 0; k < 4; k++) {
+            aa.nk[2 * k] = aa.nk[2 * k + 1] = d.nk[k];
+            aa.g[2 * k] = d.enabled[k] ? gin[k] : nullptr;
+            aa.g[2 * k + 1] = d.enabled[k] ? gsin[k] : nullptr;
+        }
+        aa.sh_in_flags = d.enabled[4];
+        aa.sh_a = d.enabled[4] ? gin[4] : nullptr; aa.sh_b = d.enabled[4] ? gsin[4] : nullptr;
+        aa.rows = w.rows; aa.ctr = w.ctr;
+        d.rows = w.rows; d.n_act = w.ctr + 2;
+    }
+    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0, &za, compact ? &aa : nullptr)) return ED3DGS_ERR_HIP;
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.emb = embedding;
     const float *gg[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
@@ -4147,8 +4303,9 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                     const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
                     const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
                     d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
+                    d.no_tail = getenv("ED3DGS_DEFORM_NO_TAIL") ? 1 : 0;
                     d.tail_split = (d.rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && d.rem_units * 2 <= G &&
-                                    !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
+                                    !d.no_tail) ? 1 : 0;
                     if (d.tail_split && !tail_zeroed) {   // the tail groups' rows of dL/d embedding are accumulated by two units each
                         const size_t r0 = (size_t)d.full_rounds * G * 128;
                         okp = check_hip(hipMemsetAsync(g_embedding + r0 * cfg->E, 0, ((size_t)cfg->P - r0) * cfg->E * sizeof(float), s), "memset g_emb tail");
@@ -4194,6 +4351,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         Dw1Args dw1;
         std::memset(&dw1, 0, sizeof dw1);
         dw1.P = cfg->P;
+        dw1.rows = d.rows; dw1.n_act = d.n_act;
         std::vector<HeadJob> hjobs;
         for (int st = 0; st < 2; st++) {
             if (!cfg->use_stage[st]) continue;
@@ -4271,6 +4429,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         HeadWgradArgs ha;
         std::memset(&ha, 0, sizeof ha);
         ha.P = cfg->P;
+        ha.rows = d.rows; ha.n_act = d.n_act;
         for (const HeadJob &J : hjobs)
             if ((J.nk > 4) == (wide != 0)) ha.job[ha.njobs++] = J;
         if (!ha.njobs) continue;
@@ -4284,7 +4443,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const bool b3 = use_b3(cfg);
         const int sub = wide ? ED3DGS_PROF_DEFORM_WGRAD_WIDE : ED3DGS_PROF_DEFORM_WGRAD_NARROW;
         const bool ps = prof_start(sub, s);
-        const bool tr_form = fwd_pieces(cfg) == 3 && !getenv("ED3DGS_DEFORM_WGRAD_R1");   // round-2 kernels (exact three-piece mode)
+        const bool tr_form = fwd_pieces(cfg) == 3 && !getenv("ED3DGS_DEFORM_WGRAD_R1") && cfg->P < (1 << 23);   // 32-bit element offsets in these kernels   // round-2 kernels (exact three-piece mode)
         if (tr_form) {
             static unsigned long long *wg_timing = nullptr;
             if (getenv("ED3DGS_WG_TIMING") && !wg_timing) (void)hipMalloc((void **)&wg_timing, 2 * 32 * sizeof(unsigned long long));

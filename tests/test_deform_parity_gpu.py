@@ -118,9 +118,16 @@ def test_golden_values_and_grads(path, mode, monkeypatch):
     # the f32-operand MFMA kernels
     (5000, 128, True, dict(f32=True)), (5000, 128, False, dict(f32=True)), (65836, 128, True, dict(f32=True, no_dr=True)),
     (777, 64, True, dict(f32=True)),
+    # the backward over the active rows only (csrc/deform.hip deform_active_rows_body): most upstream rows exactly zero, as
+    # render()'s backward delivers them for occluded / culled Gaussians; a single active row; none at all; and the dense
+    # walk (ED3DGS_DEFORM_DENSE_BWD=1) of the same sparse case
+    (65836, 128, True, dict(sparse=0.6)), (70001, 128, True, dict(sparse=0.97, no_dr=True)), (5000, 128, True, dict(sparse=-1)),
+    (5000, 128, True, dict(sparse=1.0)), (65836, 128, True, dict(sparse=0.6, dense_bwd=True)),
+    (65836, 128, True, dict(sparse=0.6, no_coarse_deform=True)),
 ], ids=["5k", "5k-stateless", "w64", "tail", "tail-no_dr-no_dc", "tail-fine-only-no_ds", "tail-coarse-only-stateless",
         "5k-split-bf16", "tail-split-bf16-no_dr", "w64-split-bf16",
-        "5k-fp32-mfma", "5k-stateless-fp32-mfma", "tail-fp32-mfma-no_dr", "w64-fp32-mfma"])
+        "5k-fp32-mfma", "5k-stateless-fp32-mfma", "tail-fp32-mfma-no_dr", "w64-fp32-mfma",
+        "sparse60", "sparse97-no_dr", "one-active-row", "no-active-row", "sparse60-dense-walk", "sparse60-fine-only"])
 def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
     keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
@@ -135,6 +142,10 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
         monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
     if flags.pop("f32", False):
         monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
+    sparse = flags.pop("sparse", 0.0)
+    monkeypatch.delenv("ED3DGS_DEFORM_DENSE_BWD", raising=False)
+    if flags.pop("dense_bwd", False):
+        monkeypatch.setenv("ED3DGS_DEFORM_DENSE_BWD", "1")
     a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
     torch.manual_seed(5)
     net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
@@ -155,6 +166,11 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     # they are taken out of the loss (both paths), so every compared gradient is well-conditioned.
     off_kink = (mg[0] > 1e-6).float()
     assert off_kink.mean() > 0.9
+    if sparse > 0:       # rows whose upstream gradient is exactly zero in every tensor
+        off_kink = off_kink * (torch.rand(P, generator=g) >= sparse).float()
+    elif sparse < 0:     # exactly one active row
+        one = torch.zeros(P); one[int(off_kink.argmax()) if P < 3000 else int(torch.nonzero(off_kink)[2999])] = 1.0
+        off_kink = off_kink * one
     ws = [mk(*x.shape) * off_kink.reshape(-1, *([1] * (x.dim() - 1))) for x in list(fin) + list(sub)]
     loss = sum((x * w.double()).sum() for x, w in zip(list(fin) + list(sub), ws))
     loss.backward()
@@ -174,9 +190,13 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     for name, p in net.named_parameters():
         ref = sd64[name].grad
         if ref is None or float(ref.abs().max()) == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
         errs["g_" + name] = rel(p.grad.cpu().numpy(), ref.numpy())
     for k in base:
+        if float(b64[k].grad.abs().max()) == 0:
+            assert float(bg[k].grad.abs().max()) == 0.0, k
+            continue
         errs["gin_" + k] = rel(bg[k].grad.cpu().numpy(), b64[k].grad.numpy())
     print("P", P, "W", W, "max err", max(errs.values()), "worst", max(errs, key=errs.get))
     for k, v in errs.items():
