@@ -196,7 +196,7 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
 extern "C" {
 
 const char *ed3dgs_last_error(void) { return g_error.c_str(); }
-int ed3dgs_abi_version(void) { return 2; }
+int ed3dgs_abi_version(void) { return 3; }
 
 size_t ed3dgs_geometry_bytes(int P)
 {

@@ -93,6 +93,7 @@ struct DeformDev {
     const float *frag[2];   // fragment workspace per stage
     FragLayout fl;
     const float *emb, *xyz, *scales, *rot, *opacity, *sh;
+    const float *sh_rest;   // NULL: sh is [P][n_sh][3]; else sh is the DC term [P][1][3] and this the rest [P][n_sh - 1][3]
     float *out[5], *sub[5];
     // backward
     const float *g[5], *gs[5];
@@ -533,6 +534,22 @@ __device__ __forceinline__ f32x16 gemm_tile(const float *__restrict__ frag, cons
 }
 
 // the lane's 16 embedding features in k-slot order: 4 float4 at offsets 4h + 8q
+// four consecutive SH values (features feat .. feat + 3 of Gaussian g's row of shw = 3 n_sh) from the whole tensor or from
+// the reference's split storage (_features_dc [P,1,3] / _features_rest [P,n_sh-1,3], scene/gaussian_model.py:57-58, whose
+// concatenation get_features :128-131 would otherwise be a copy of both per call): rows of the rest tensor are only
+// 4-byte aligned
+__device__ __forceinline__ float4 load_sh4(const DeformDev &d, int g, int feat, int shw)
+{
+    if (!d.sh_rest) return *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+    const float *r = d.sh_rest + (size_t)g * (shw - 3);
+    if (feat == 0) {
+        const float *p = d.sh + (size_t)g * 3;
+        return make_float4(p[0], p[1], p[2], r[0]);
+    }
+    r += feat - 3;
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 __device__ __forceinline__ void load_emb_slots(const float *__restrict__ emb, int E, int g, int et, int h, float (&eb)[16])
 {
     const float4 *row = reinterpret_cast<const float4 *>(emb + (size_t)g * E + et * 32 + 4 * h);
@@ -570,7 +587,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int c = 0; c < 6; c++) {  // chunks: tile c>>2, q = c&3 -> features (c>>2)*32 + 8q + 4h
             const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
             float4 v = make_float4(0, 0, 0, 0);
-            if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+            if (feat < shw) v = load_sh4(d, g, feat, shw);
             csh[4 * c] = v.x; csh[4 * c + 1] = v.y; csh[4 * c + 2] = v.z; csh[4 * c + 3] = v.w;
         }
         for (int s = 0; s < 2; s++) {
@@ -1020,7 +1037,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int cc = 0; cc < 6; cc++) {
             const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
             float4 v = make_float4(0, 0, 0, 0);
-            if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+            if (feat < shw) v = load_sh4(d, g, feat, shw);
             csh[4 * cc] = v.x; csh[4 * cc + 1] = v.y; csh[4 * cc + 2] = v.z; csh[4 * cc + 3] = v.w;
         }
         float eb[1][16];
@@ -1319,7 +1336,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int cc = 0; cc < 6; cc++) {
             const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
             float4 v = make_float4(0, 0, 0, 0);
-            if (feat < shw) v = *reinterpret_cast<const float4 *>(d.sh + (size_t)g * shw + feat);
+            if (feat < shw) v = load_sh4(d, g, feat, shw);
             csh[4 * cc] = v.x; csh[4 * cc + 1] = v.y; csh[4 * cc + 2] = v.z; csh[4 * cc + 3] = v.w;
         }
 #pragma unroll 1
@@ -3774,6 +3791,7 @@ __device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, con
             }
         }
     }
+    if (!a.rows) return;   // split output only (a configuration whose backward walks every row)
     __syncthreads();
     const bool act = tid < nrow && fl[tid] != 0;
     const unsigned long long bal = __ballot(act);
@@ -4101,8 +4119,8 @@ size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backw
 
 int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
                           const float *const params[2], const float *embedding, const float *xyz, const float *scales,
-                          const float *rot, const float *opacity, const float *sh, float *out_xyz, float *out_scales,
-                          float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
+                          const float *rot, const float *opacity, const float *sh, const float *sh_rest, float *out_xyz,
+                          float *out_scales, float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
                           float *sub_rot, float *sub_opacity, float *sub_sh, char *workspace, size_t workspace_bytes,
                           int keep_activations, void *stream)
 {
@@ -4131,7 +4149,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     if (getenv("ED3DGS_FWD_TIMING") && !fwd_timing) (void)hipMalloc((void **)&fwd_timing, 32 * sizeof(unsigned long long));
     d.timing = getenv("ED3DGS_FWD_TIMING") ? fwd_timing : nullptr;
     if (keep) for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.MK[st] = w.MK[st]; }
-    d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh;
+    d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh; d.sh_rest = sh_rest;
     float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
     float *subs[5] = {sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh};
     for (int i = 0; i < 5; i++) { d.out[i] = outs[i]; d.sub[i] = have_sub ? subs[i] : nullptr; }
@@ -4184,13 +4202,15 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            const float *g_scales, const float *g_rot, const float *g_opacity, const float *g_sh,
                            const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
                            const float *gs_sh, float *const gparams[2], float *g_table, float *g_offsets,
-                           float *g_embedding, char *workspace, size_t workspace_bytes, int activations_kept,
-                           void *stream)
+                           float *g_embedding, float *g_base_sh_dc, float *g_base_sh_rest, char *workspace,
+                           size_t workspace_bytes, int activations_kept, void *stream)
 {
     if (!validate(cfg, "ed3dgs_deform_backward")) return ED3DGS_ERR_INVALID;
     if (activations_kept && !can_keep(cfg)) { set_error("ed3dgs_deform_backward: activations_kept set for a configuration that does not keep them"); return ED3DGS_ERR_INVALID; }
     if (cfg->E != 32) { set_error("ed3dgs_deform_backward: gaussian_embedding_dim must be 32"); return ED3DGS_ERR_INVALID; }
     if (!table || !offsets || !g_table || !g_offsets || !workspace) { set_error("ed3dgs_deform_backward: null pointer"); return ED3DGS_ERR_INVALID; }
+    if ((g_base_sh_dc == nullptr) != (g_base_sh_rest == nullptr)) { set_error("ed3dgs_deform_backward: g_base_sh_dc and g_base_sh_rest must both be set or both be NULL"); return ED3DGS_ERR_INVALID; }
+    if (g_base_sh_dc && !g_sh && !gs_sh) { set_error("ed3dgs_deform_backward: split dL/d SH requested without g_sh / gs_sh"); return ED3DGS_ERR_INVALID; }
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && (!params[s] || !gparams[s])) { set_error("ed3dgs_deform_backward: null params"); return ED3DGS_ERR_INVALID; }
     if (workspace_bytes < carve(cfg, true, nullptr, nullptr)) { set_error("ed3dgs_deform_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
@@ -4235,21 +4255,26 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     fill_dev(cfg, d, true);
     ActiveArgs aa;
     std::memset(&aa, 0, sizeof aa);
-    if (compact) {
+    const bool split_sh = g_base_sh_dc != nullptr;
+    if (compact || split_sh) {
         const float *gin[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
         const float *gsin[5] = {gs_xyz, gs_scales, gs_rot, gs_opacity, gs_sh};
         aa.P = cfg->P; aa.nblk = (cfg->P + 255) / 256; aa.shw = 3 * cfg->n_sh;
         for (int k = 0; k < 4; k++) {
             aa.nk[2 * k] = aa.nk[2 * k + 1] = d.nk[k];
-            aa.g[2 * k] = d.enabled[k] ? gin[k] : nullptr;
-            aa.g[2 * k + 1] = d.enabled[k] ? gsin[k] : nullptr;
+            aa.g[2 * k] = (compact && d.enabled[k]) ? gin[k] : nullptr;
+            aa.g[2 * k + 1] = (compact && d.enabled[k]) ? gsin[k] : nullptr;
         }
-        aa.sh_in_flags = d.enabled[4];
-        aa.sh_a = d.enabled[4] ? gin[4] : nullptr; aa.sh_b = d.enabled[4] ? gsin[4] : nullptr;
-        aa.rows = w.rows; aa.ctr = w.ctr;
-        d.rows = w.rows; d.n_act = w.ctr + 2;
+        aa.sh_in_flags = compact && d.enabled[4];
+        const bool want_sh = aa.sh_in_flags || split_sh;
+        aa.sh_a = want_sh ? gin[4] : nullptr; aa.sh_b = want_sh ? gsin[4] : nullptr;
+        aa.sh_dc = g_base_sh_dc; aa.sh_rest = g_base_sh_rest;
+        if (compact) {
+            aa.rows = w.rows; aa.ctr = w.ctr;
+            d.rows = w.rows; d.n_act = w.ctr + 2;
+        }
     }
-    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0, &za, compact ? &aa : nullptr)) return ED3DGS_ERR_HIP;
+    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0, &za, (compact || split_sh) ? &aa : nullptr)) return ED3DGS_ERR_HIP;
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.emb = embedding;
     const float *gg[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};

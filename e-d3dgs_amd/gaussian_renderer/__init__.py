@@ -60,7 +60,14 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     opacity = pc._opacity
-    shs = pc.get_features
+    # the model's split SH storage goes to the deformation as it is (scene/gaussian_model.py:57-58): get_features (:128-131)
+    # would copy both tensors into one per call, and autograd would copy the gradient back out of it slice by slice
+    shs_rest = None
+    if (torch.is_tensor(getattr(pc, "_features_dc", None)) and torch.is_tensor(getattr(pc, "_features_rest", None))
+            and pc._features_dc.dim() == 3 and pc._features_rest.dim() == 3 and pc._features_rest.shape[1] > 0):
+        shs, shs_rest = pc._features_dc, pc._features_rest
+    else:
+        shs = pc.get_features
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
@@ -70,7 +77,7 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
 
     (means3D_final, scales_final, rotations_final, opacity_final, shs_final, extras) = pc._deformation(
         means3D, scales, rotations, opacity, float(viewpoint_camera.time), cam_no, pc, None, shs, iter=iter,
-        num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f)
+        num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f, sh_coefs_rest=shs_rest)
 
     if scales_final is not None and _standard_activations(pc) and (disable_filter3D or getattr(pc, "fused_filter3D", False)):
         # one fused launch per direction (csrc/activations.hip) instead of normalize / exp / sigmoid (/ 3D filter)

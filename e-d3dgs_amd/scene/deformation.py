@@ -29,10 +29,11 @@ def _c32(t):
 
 class _DeformFn(torch.autograd.Function):
     """forward/backward of both stages as C-ABI calls.  Differentiable inputs: temporal table, offsets, the two packed
-    parameter blocks, Gaussian embedding, and the five base tensors."""
+    parameter blocks, Gaussian embedding, and the five base tensors -- the SH one either whole (`sh` [P,n_sh,3],
+    `sh_rest` None) or as the reference stores it (`sh` = _features_dc [P,1,3], `sh_rest` = _features_rest [P,n_sh-1,3])."""
 
     @staticmethod
-    def forward(ctx, cfgd, want_sub, keep, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh):
+    def forward(ctx, cfgd, want_sub, keep, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh, sh_rest):
         L = _lib.lib()
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward (NULL = zero for the C ABI)
         cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
@@ -41,10 +42,12 @@ class _DeformFn(torch.autograd.Function):
         dev = xyz.device
         if not xyz.is_cuda:
             raise RuntimeError("deform_network: tensors must be on the GPU (the MI355X path has no CPU fallback)")
-        ins = [_c32(t) for t in (table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh)]
-        table_, offsets_, fc, ff, emb_, xyz_, sc_, rot_, op_, sh_ = ins
-        outs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_, sh_)]
-        subs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_, sh_)] if want_sub else [None] * 5
+        ins = [_c32(t) for t in (table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh, sh_rest)]
+        table_, offsets_, fc, ff, emb_, xyz_, sc_, rot_, op_, sh_, shr_ = ins
+        P = xyz_.shape[0]
+        sh_shape = (P, cfgd["n_sh"], 3)
+        outs = [torch.empty_like(t) for t in (xyz_, sc_, rot_, op_)] + [torch.empty(sh_shape, device=dev)]
+        subs = ([torch.empty_like(t) for t in (xyz_, sc_, rot_, op_)] + [torch.empty(sh_shape, device=dev)]) if want_sub else [None] * 5
         # training: the forward keeps the hidden activations in the backward's workspace (as autograd does for the
         # reference's Linear/ReLU modules); inference: small workspace, nothing kept
         ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1 if keep else 0))
@@ -52,7 +55,7 @@ class _DeformFn(torch.autograd.Function):
         params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
         rc = L.ed3dgs_deform_forward(
             C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
-            _ptr(sh_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
+            _ptr(sh_), _ptr(shr_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
             C.c_int(1 if keep else 0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
@@ -61,6 +64,7 @@ class _DeformFn(torch.autograd.Function):
         ctx.want_sub = want_sub
         ctx.save_for_backward(table_, offsets_, fc, ff, emb_)
         ctx.shapes = [t.shape for t in (table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh)]
+        ctx.split_sh = None if sh_rest is None else (sh.shape, sh_rest.shape)
         if want_sub:
             return tuple(outs) + tuple(subs)
         return tuple(outs)
@@ -81,6 +85,12 @@ class _DeformFn(torch.autograd.Function):
         g_table = torch.empty_like(table_)
         g_off = torch.empty_like(offsets_)
         g_emb = torch.empty_like(emb_)
+        # split SH storage: dL/d(_features_dc) and dL/d(_features_rest) come out of the pass that reads the upstream
+        # gradients (contiguous tensors autograd can hand to the parameters as they are)
+        g_dc = g_rest = None
+        if ctx.split_sh is not None and (g_out[4] is not None or g_sub[4] is not None):
+            g_dc = torch.empty(ctx.split_sh[0], device=dev)
+            g_rest = torch.empty(ctx.split_sh[1], device=dev)
         ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1))
         kept = ctx.kept_ws is not None
         ws = ctx.kept_ws if kept else torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -89,7 +99,7 @@ class _DeformFn(torch.autograd.Function):
         gparams = (C.c_void_p * 2)(gfc.data_ptr() if cfgd["use_stage"][0] else None, gff.data_ptr() if cfgd["use_stage"][1] else None)
         rc = L.ed3dgs_deform_backward(
             C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), *[_ptr(g) for g in g_out],
-            *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(ws),
+            *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(g_dc), _ptr(g_rest), _ptr(ws),
             C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
@@ -98,10 +108,14 @@ class _DeformFn(torch.autograd.Function):
         if not cfgd["use_stage"][1]:
             gff.zero_()
         base = []
-        for i in range(5):  # identity paths: out = base + ..., sub = base + ...
+        for i in range(4 if ctx.split_sh is not None else 5):  # identity paths: out = base + ..., sub = base + ...
             a, b = gr[i], (gr[5 + i] if ctx.want_sub else None)
             g = a if b is None else (b if a is None else a + b)
             base.append(None if g is None else g.reshape(ctx.shapes[5 + i]))
+        if ctx.split_sh is not None:
+            base += [g_dc, g_rest]
+        else:
+            base.append(None)
         sh = ctx.shapes
         return (None, None, None, g_table.reshape(sh[0]), g_off.reshape(sh[1]), gfc.reshape(sh[2]), gff.reshape(sh[3]),
                 g_emb.reshape(sh[4]), *base)
@@ -178,12 +192,18 @@ class deform_network(nn.Module):
         return n_c, c2f(num_down_emb_f)
 
     def forward(self, point, scales=None, rotations=None, opacity=None, time_emb=None, cam_no=None, pc=None,
-                embeddings=None, sh_coefs=None, iter=None, num_down_emb_c=30, num_down_emb_f=30, want_extras=True):
+                embeddings=None, sh_coefs=None, iter=None, num_down_emb_c=30, num_down_emb_f=30, want_extras=True,
+                sh_coefs_rest=None):
+        """The reference's signature (:108-141) plus two keywords.  `sh_coefs_rest`: pass the model's split SH storage
+        as it is -- sh_coefs = _features_dc [P,1,3], sh_coefs_rest = _features_rest [P,n_sh-1,3] -- instead of their
+        concatenation (get_features, scene/gaussian_model.py:128-131): the kernels read both and the backward writes both
+        gradients, so neither the concatenation nor autograd's two slice copies run.  The last element of the returned
+        `orig` tuple is then the pair (sh_coefs, sh_coefs_rest)."""
         a = self.args
         if self.D > 1:
             raise NotImplementedError("defor_depth > 1 is not supported by the fused MI355X deformation path")
         pts, scales, rotations, opacity = point[:, :3], scales[:, :3], rotations[:, :4], opacity[:, :1]
-        orig = (pts, scales, rotations, opacity, sh_coefs)
+        orig = (pts, scales, rotations, opacity, sh_coefs if sh_coefs_rest is None else (sh_coefs, sh_coefs_rest))
         emb = embeddings if pc is None else pc.get_embedding
         # the reference reads only time_emb[0, 0] (:58); a Python float avoids the device read-back
         time = float(time_emb) if not torch.is_tensor(time_emb) else float(time_emb.reshape(-1)[0])
@@ -192,14 +212,14 @@ class deform_network(nn.Module):
         coef_x = 1.0 if not use_anneal else float(np.clip((iter - a.deform_from_iter) / 1000, 0, 1))
         n_c, n_f = self._row_counts(iter, num_down_emb_c, num_down_emb_f)
         cfgd = dict(P=pts.shape[0], W=self.W, D=self.D, E=self.gaussian_embedding_dim, TD=self.temporal_embedding_dim,
-                    n_sh=sh_coefs.shape[1], max_embeddings=self.max_embeddings, num_offsets=self.offsets.shape[0],
+                    n_sh=sh_coefs.shape[1] + (0 if sh_coefs_rest is None else sh_coefs_rest.shape[1]), max_embeddings=self.max_embeddings, num_offsets=self.offsets.shape[0],
                     use_stage=(int(not a.no_coarse_deform), int(not a.no_fine_deform)), n_rows=(int(n_c), int(n_f)),
                     no_ds=int(a.no_ds), no_dr=int(a.no_dr), no_do=int(a.no_do), no_dc=int(a.no_dc), coef=coef,
                     coef_c=coef_x, coef_o=coef_x, coef_s=coef_x, time=time, cam_no=-1 if cam_no is None else int(cam_no))
         args = (self.weight, self.offsets, self._flat_stage("c"), self._flat_stage("f"), emb, pts, scales, rotations,
-                opacity, sh_coefs)
+                opacity, sh_coefs, sh_coefs_rest)
         # decided here: inside autograd.Function.forward grad mode is off
-        keep = KEEP_ACTIVATIONS and torch.is_grad_enabled() and any(t.requires_grad for t in args)
+        keep = KEEP_ACTIVATIONS and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args)
         res = _DeformFn.apply(cfgd, bool(want_extras), bool(keep), *args)
         final = res[:5]
         sub = res[5:10] if want_extras else orig

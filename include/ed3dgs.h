@@ -257,6 +257,8 @@ size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backw
 /*
  * Forward.  table[max_embeddings][TD], offsets[num_offsets], params[2] (coarse, fine; NULL if the stage is off),
  * embedding[P][E], base tensors xyz[P,3], scales[P,3], rot[P,4], opacity[P], sh[P,n_sh,3].
+ * sh_rest == NULL: `sh` is the whole SH tensor.  sh_rest != NULL: the reference's split storage (scene/gaussian_model.py:57-58):
+ * `sh` = _features_dc [P,1,3], `sh_rest` = _features_rest [P,n_sh-1,3]; saves the caller get_features' concatenation (:128-131).
  * out_*: values after both stages; sub_*: values after the coarse stage (extras[0], :139-141), may be NULL.
  * keep_activations != 0 (training): the hidden activations (relu(hid), relu(z_k); 3 KB per Gaussian and stage) are
  * written into the workspace for ed3dgs_deform_backward, as autograd keeps them for the reference's Linear/ReLU
@@ -267,7 +269,7 @@ size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backw
 int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
                           const float *const params[2], const float *embedding, const float *xyz,
                           const float *scales, const float *rot, const float *opacity, const float *sh,
-                          float *out_xyz, float *out_scales, float *out_rot, float *out_opacity, float *out_sh,
+                          const float *sh_rest, float *out_xyz, float *out_scales, float *out_rot, float *out_opacity, float *out_sh,
                           float *sub_xyz, float *sub_scales, float *sub_rot, float *sub_opacity, float *sub_sh,
                           char *workspace, size_t workspace_bytes, int keep_activations, void *stream);
 
@@ -276,7 +278,11 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
  * forward of the same inputs filled with keep_activations.  g_* = dL/d(out_*), gs_* = dL/d(sub_*); NULL = zero.
  * Every output is fully written: gparams[2] (packed like params), g_table[max_embeddings][TD],
  * g_offsets[num_offsets], g_embedding[P][E].  Gradients w.r.t. the base tensors are g_* + gs_* (identity paths)
- * and are left to the caller.
+ * and are left to the caller -- except, on request, the SH one: g_base_sh_dc [P,1,3] / g_base_sh_rest [P,n_sh-1,3] (both or
+ * neither; requires g_sh or gs_sh) receive g_sh + gs_sh in the split layout of ed3dgs_deform_forward's sh / sh_rest, written
+ * by the pass that reads the upstream gradients anyway (autograd would copy both strided slices otherwise).
+ * Rows of the upstream gradients that are entirely zero (Gaussians no pixel blended) are skipped by the kept-activation
+ * backward: their contribution to every output is exactly zero.
  */
 int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
                            const float *const params[2], const float *embedding,
@@ -285,7 +291,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
                            const float *gs_sh,
                            float *const gparams[2], float *g_table, float *g_offsets, float *g_embedding,
-                           char *workspace, size_t workspace_bytes, int activations_kept, void *stream);
+                           float *g_base_sh_dc, float *g_base_sh_rest, char *workspace, size_t workspace_bytes, int activations_kept, void *stream);
 
 #ifdef __cplusplus
 }

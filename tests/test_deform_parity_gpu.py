@@ -203,6 +203,66 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
         assert v <= TOL, (k, v)
 
 
+@pytest.mark.parametrize("P,flags,loss_on_sub", [(5000, {}, True), (65836, {}, False), (5000, dict(no_dc=True), True),
+                                                 (5000, dict(f32=True), True), (777, dict(stateless=True), True)],
+                         ids=["5k", "tail-no-sub-loss", "no_dc", "fp32-mfma", "stateless"])
+def test_split_sh_storage_matches_whole(P, flags, loss_on_sub, monkeypatch):
+    """forward(sh_coefs=_features_dc, sh_coefs_rest=_features_rest) against forward(sh_coefs=cat(dc, rest)): identical
+    outputs (bit for bit: the same arithmetic on the same values), dL/d dc and dL/d rest equal to the slices of the whole
+    tensor's gradient (bit for bit: g_sh + gs_sh either way), parameter gradients equal up to the order of the atomic sums."""
+    _need_gpu()
+    from oracle import deformation_ref as R
+    import scene.deformation as SD
+    from scene.deformation import deform_network
+    flags = dict(flags)
+    if flags.pop("f32", False):
+        monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
+    monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", not flags.pop("stateless", False))
+    a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
+    torch.manual_seed(11)
+    net = deform_network(D=1, W=128, min_embeddings=30, max_embeddings=150, num_frames=300, args=a).cuda()
+    with torch.no_grad():
+        net.weight.mul_(100.0)
+    g = torch.Generator().manual_seed(12)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+    base = dict(xyz=mk(P, 3), scales=mk(P, 3, sc=0.3) - 4, rot=mk(P, 4), opacity=mk(P, 1), dc=mk(P, 1, 3), rest=mk(P, 15, 3, sc=0.2),
+                emb=mk(P, 32, sc=0.1))
+    ws = [mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 1), mk(P, 16, 3)]
+    ws_sub = [mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 1), mk(P, 16, 3)]
+    dead = (torch.rand(P, generator=g) < 0.5).cuda()          # rows without any upstream gradient, as render() delivers them
+    for w in ws + ws_sub:
+        w[dead] = 0
+
+    def run(split):
+        net.zero_grad(set_to_none=True)
+        b = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        if split:
+            outs = net(b["xyz"], b["scales"], b["rot"], b["opacity"], 0.37, None, _PC(b["emb"]), None, b["dc"], iter=20000,
+                       num_down_emb_c=30, num_down_emb_f=30, sh_coefs_rest=b["rest"])
+            assert isinstance(outs[5][1][4], tuple) and outs[5][1][4][1] is b["rest"]
+        else:
+            whole = torch.cat((b["dc"], b["rest"]), 1)
+            outs = net(b["xyz"], b["scales"], b["rot"], b["opacity"], 0.37, None, _PC(b["emb"]), None, whole, iter=20000,
+                       num_down_emb_c=30, num_down_emb_f=30)
+        fin, sub = outs[:5], outs[5][0]
+        loss = sum((x * w).sum() for x, w in zip(fin, ws))
+        if loss_on_sub:
+            loss = loss + sum((x * w).sum() for x, w in zip(sub, ws_sub))
+        loss.backward()
+        return ([x.detach().clone() for x in list(fin) + list(sub)], {k: v.grad.clone() for k, v in b.items()},
+                {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+
+    o1, g1, p1 = run(False)
+    o2, g2, p2 = run(True)
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    assert float(g2["dc"][dead].abs().max()) == 0.0 and float(g2["rest"][~dead].abs().max()) > 0
+    for n in p1:
+        assert float((p1[n] - p2[n]).abs().max()) <= 1e-5 * max(float(p1[n].abs().max()), 1e-30), n
+
+
 @pytest.mark.parametrize("with_filter", [False, True])
 def test_fused_activations_match_torch(with_filter):
     """a7 (scene/gaussian_model.py:37-45, 594-603): the fused HIP activation kernel against the torch ops the

@@ -330,7 +330,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, missing
     assert set(_lib.EXPORTS) >= declared - {"ed3dgs_deform_cfg", "ed3dgs_state_view"}
-    assert L.ed3dgs_abi_version() == 2
+    assert L.ed3dgs_abi_version() == 3
     assert L.ed3dgs_backward_workspace_bytes(1000, 0) >= 1000 * 64
 
 
