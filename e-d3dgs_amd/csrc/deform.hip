@@ -3749,7 +3749,9 @@ struct ActiveArgs {
     const float *sh_a, *sh_b;     // g_sh, gs_sh
     float *sh_dc, *sh_rest;       // optional split output of g_sh + gs_sh
     int *rows, *ctr;
+    const float *dummy;           // >= 16 readable bytes standing in for absent tensors
 };
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte access at a 4-byte aligned address
 __device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, const int bx)
 {
     __shared__ int fl[256];
@@ -3759,34 +3761,60 @@ __device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, con
     const int g0 = bx * 256, nrow = min(256, a.P - g0);
     fl[tid] = 0;
     __syncthreads();
-    for (int q = 0; q < 8; q++) {
-        const float *p = a.g[q];
-        if (!p) continue;
-        const int nk = a.nk[q], n = nrow * nk;
-        p += (size_t)g0 * nk;
-        for (int e = tid; e < n; e += 256)
-            if (p[e] != 0.f) fl[e / nk] = 1;
+    // Every load below is unconditional (an absent tensor reads one valid dummy word and is ignored), so that a thread's loads
+    // are all in flight together: with a load / test / store chain per element this pass was latency-bound (117 us at 200k).
+    const float *dummy = a.dummy;
+    {   // narrow heads: thread = Gaussian, up to 4 values of each of the 8 tensors
+        const int row = min(tid, nrow - 1);
+        float v[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int nkq = a.g[q] ? a.nk[q] : 1;                        // absent: one dummy word, four times
+            const float *p = a.g[q] ? a.g[q] + (size_t)(g0 + row) * nkq : dummy;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[q][j] = p[min(j, nkq - 1)];   // values past nk re-read the last one
+        }
+        bool nz = false;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) nz |= (a.g[q] != nullptr) & (v[q][j] != 0.f);
+        if (nz) fl[row] = 1;
     }
-    if (a.sh_a || a.sh_b) {
+    if (a.sh_a || a.sh_b) {   // SH rows: coalesced 16-byte chunks, chunk idx = tid + 256 j of the block's nrow * shw / 4
         const int c4 = a.shw >> 2, n = nrow * c4, rw = a.shw - 3;
-        for (int idx = tid; idx < n; idx += 256) {
-            const size_t o = (size_t)g0 * a.shw + (size_t)idx * 4;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (a.sh_a) va = *reinterpret_cast<const float4 *>(a.sh_a + o);
-            if (a.sh_b) vb = *reinterpret_cast<const float4 *>(a.sh_b + o);
-            const int row = idx / c4, c = idx - row * c4;
-            const bool nz = va.x != 0.f || va.y != 0.f || va.z != 0.f || va.w != 0.f || vb.x != 0.f || vb.y != 0.f || vb.z != 0.f || vb.w != 0.f;
-            if (a.sh_in_flags && nz) fl[row] = 1;
-            if (a.sh_dc) {
-                const float4 v = a.sh_b ? make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w) : va;
-                const size_t gr = (size_t)(g0 + row);
-                if (c == 0) {
-                    float *d3 = a.sh_dc + gr * 3;
-                    d3[0] = v.x; d3[1] = v.y; d3[2] = v.z;
-                    a.sh_rest[gr * rw] = v.w;
-                } else {
-                    float *r4 = a.sh_rest + gr * rw + 4 * c - 3;
-                    r4[0] = v.x; r4[1] = v.y; r4[2] = v.z; r4[3] = v.w;
+        const float *pa = a.sh_a ? a.sh_a + (size_t)g0 * a.shw : dummy, *pb = a.sh_b ? a.sh_b + (size_t)g0 * a.shw : dummy;
+        const int sa = a.sh_a ? 4 : 0, sb = a.sh_b ? 4 : 0;
+#pragma unroll 1
+        for (int j0 = 0; j0 < 16; j0 += 8) {
+            if (j0 * 256 >= n) break;
+            float4 va[8], vb[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int idx = min(tid + 256 * (j0 + j), n - 1);
+                va[j] = *reinterpret_cast<const float4 *>(pa + (size_t)idx * sa);
+                vb[j] = *reinterpret_cast<const float4 *>(pb + (size_t)idx * sb);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int idx = tid + 256 * (j0 + j);
+                if (idx >= n) continue;
+                const int row = idx / c4, c = idx - row * c4;
+                const bool nza = a.sh_a && (va[j].x != 0.f || va[j].y != 0.f || va[j].z != 0.f || va[j].w != 0.f);
+                const bool nzb = a.sh_b && (vb[j].x != 0.f || vb[j].y != 0.f || vb[j].z != 0.f || vb[j].w != 0.f);
+                if (a.sh_in_flags && (nza || nzb)) fl[row] = 1;
+                if (a.sh_dc) {
+                    float4 v = a.sh_a ? va[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.sh_b) { v.x += vb[j].x; v.y += vb[j].y; v.z += vb[j].z; v.w += vb[j].w; }
+                    const size_t gr = (size_t)(g0 + row);
+                    if (c == 0) {
+                        float *d3 = a.sh_dc + gr * 3;
+                        d3[0] = v.x; d3[1] = v.y; d3[2] = v.z;
+                        a.sh_rest[gr * rw] = v.w;
+                    } else {
+                        f32x4u o4 = {v.x, v.y, v.z, v.w};
+                        *reinterpret_cast<f32x4u *>(a.sh_rest + gr * rw + 4 * c - 3) = o4;
+                    }
                 }
             }
         }
@@ -3805,14 +3833,15 @@ __device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, con
     int off = base_s;
     for (int w = 0; w < wave; w++) off += wsum[w];
     if (act) a.rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = g0 + tid;
-    __threadfence();
-    __syncthreads();
+    // No fence: nothing a block writes is read by another block of this launch (the list and the count are for the next
+    // kernels; a device-scope release here would write back the whole L2 of the XCD -- the pass took 117 us with one).  The
+    // counters are touched by atomics only, and thread 0 has consumed the cursor atomic's result before it takes its ticket.
     if (tid == 0) {
         const int t = atomicAdd(&a.ctr[1], 1);
         if (t == a.nblk - 1) {   // last block: publish the count, re-arm the counters
             const int n = atomicAdd(&a.ctr[0], 0);
-            a.ctr[2] = n; a.ctr[0] = 0; a.ctr[1] = 0;
-            __threadfence();
+            a.ctr[2] = n;
+            atomicExch(&a.ctr[0], 0); atomicExch(&a.ctr[1], 0);
         }
     }
 }
@@ -4269,6 +4298,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const bool want_sh = aa.sh_in_flags || split_sh;
         aa.sh_a = want_sh ? gin[4] : nullptr; aa.sh_b = want_sh ? gsin[4] : nullptr;
         aa.sh_dc = g_base_sh_dc; aa.sh_rest = g_base_sh_rest;
+        aa.dummy = w.fs;
         if (compact) {
             aa.rows = w.rows; aa.ctr = w.ctr;
             d.rows = w.rows; d.n_act = w.ctr + 2;

@@ -40,11 +40,11 @@ __global__ void __launch_bounds__(256) image_stats_kernel(const float *__restric
     if (threadIdx.x == 0) {
         atomicAdd(acc + 0, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
         atomicAdd(acc + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
-        __threadfence();
+        // no fence between the sums and the ticket: the three words share a cache line (one L2 channel, served in order), and a
+        // device-scope release would write back the XCD's whole L2 -- the price of one per block
         const unsigned done = atomicAdd(reinterpret_cast<unsigned *>(acc + 2), 1u);
         last = done == gridDim.x - 1;
         if (last) {
-            __threadfence();
             const float a0 = atomicExch(acc + 0, 0.f), a1 = atomicExch(acc + 1, 0.f);
             atomicExch(reinterpret_cast<unsigned *>(acc + 2), 0u);
             out[0] = a0;
@@ -62,7 +62,7 @@ extern "C" int ed3dgs_image_stats(const float *image, const float *weight, size_
 {
     if (!image || !weight || !acc || !out3 || n == 0) { set_error("ed3dgs_image_stats: null pointer or empty image"); return ED3DGS_ERR_INVALID; }
     if (((uintptr_t)image | (uintptr_t)weight) & 15) { set_error("ed3dgs_image_stats: image / weight must be 16-byte aligned"); return ED3DGS_ERR_INVALID; }
-    const int blocks = (int)std::min<size_t>(256, (n / 4 + 1023) / 1024 + 1);   // few blocks: three same-address atomics per block serialise (2048 blocks: 75 us)
+    const int blocks = (int)std::min<size_t>(getenv("ED3DGS_STATS_BLOCKS") ? atoi(getenv("ED3DGS_STATS_BLOCKS")) : 256, (n / 4 + 1023) / 1024 + 1);   // few blocks: three same-line atomics per block serialise (512 blocks: 28 us, 256: 20 us)
     hipLaunchKernelGGL(image_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, weight, n, mid, acc, out3);
     return check_hip(hipGetLastError(), "image_stats") ? 0 : ED3DGS_ERR_HIP;
 }
