@@ -34,6 +34,7 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     g.scan_size = scan_temp_bytes((int)P);
     obtain(chunk, g.scan_space, g.scan_size, 128);
     obtain(chunk, g.point_offsets, P, 128);
+    obtain(chunk, g.block_tiles, (P + 255) / 256 + 1, 128);
     obtain(chunk, g.depth_keys, P, 128);
     obtain(chunk, g.depth_keys_sorted, P, 128);
     obtain(chunk, g.ids, P, 128);
@@ -137,23 +138,28 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
                       colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
                       focal_y, kernel_size, radii, geom, s, invraycov, condition);
     if (!ok("preprocess")) return ED3DGS_ERR_HIP;
-    if (!run_scan(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.point_offsets, P, s)) return ED3DGS_ERR_HIP;
-    if (!ok("scan")) return ED3DGS_ERR_HIP;
-    // The one read-back of the path (CR/rasterizer_impl.cu:359: the instance count sizes the binning buffers).  The copy
+    // The one read-back of the path (CR/rasterizer_impl.cu:359: the instance count sizes the binning buffers).  The reference
+    // scans tiles_touched for it; nothing here needs the per-Gaussian offsets (the level-2 transpose scans per tile), so the
+    // preprocess blocks leave their sums (4 bytes per 256 Gaussians) and the host adds them up -- no scan launches.  The copy
     // goes to pinned memory and is followed by an event; the work that does not need the count -- binning level 1
-    // (binning.hip: Gaussians by depth, then the instance offsets in that order) and clearing the tile ranges -- is
-    // enqueued BEHIND the copy, and the host waits for the event only.  By the time the GPU has finished the level-1
-    // sort the host has allocated the binning buffers and enqueued the rest, so the stream never runs dry (the
-    // reference's cudaMemcpy drains it).
+    // (binning.hip: Gaussians by depth) -- is enqueued BEHIND the copy, and the host waits for the event only.  By the time
+    // the GPU has finished the level-1 sort the host has allocated the binning buffers and enqueued the rest, so the stream
+    // never runs dry (the reference's cudaMemcpy drains it).
     static thread_local struct Readback {
         uint32_t *host = nullptr;
+        size_t cap = 0;
         hipEvent_t ev = nullptr;
     } rb;
-    if (!rb.host) {
-        if (!check_hip(hipHostMalloc((void **)&rb.host, 64, hipHostMallocDefault), "pinned read-back buffer") ||
-            !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
+    const size_t nblk = ((size_t)P + 255) / 256;
+    if (rb.cap < nblk) {
+        if (rb.host) (void)hipHostFree(rb.host);
+        rb.host = nullptr; rb.cap = 0;
+        const size_t cap = std::max<size_t>(4096, nblk * 2);
+        if (!check_hip(hipHostMalloc((void **)&rb.host, cap * sizeof(uint32_t), hipHostMallocDefault), "pinned read-back buffer")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
+        rb.cap = cap;
     }
-    if (!check_hip(hipMemcpyAsync(rb.host, geom.point_offsets + P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
+    if (!rb.ev && !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) return ED3DGS_ERR_HIP;
+    if (!check_hip(hipMemcpyAsync(rb.host, geom.block_tiles, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5
@@ -164,7 +170,8 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     }
     if (!ok("depth order")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
-    const uint32_t num_rendered_u = *rb.host;
+    uint64_t num_rendered_u = 0;
+    for (size_t b = 0; b < nblk; b++) num_rendered_u += rb.host[b];
     if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
     const int R = (int)num_rendered_u;
 
@@ -477,6 +484,9 @@ int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geome
     ImageState img = ImageState::from_chunk(ic, (size_t)width * height, tiles_of(width, height));
     out->rec = g.rec; out->rec_coord = g.rec_coord; out->depths = g.depths; out->cov3D = g.cov3D;
     out->clamped = g.clamped; out->tiles_touched = g.tiles_touched; out->point_offsets = g.point_offsets;
+    // the reference's point_offsets (CR/rasterizer_impl.cu:355): the product path does not need the scan; formed here for the tests
+    if (P > 0 && (!run_scan(g.scan_space, g.scan_size, g.tiles_touched, g.point_offsets, P, nullptr) ||
+                  !check_hip(hipDeviceSynchronize(), "point offsets scan"))) return ED3DGS_ERR_HIP;
     out->ranges = img.ranges; out->n_contrib = img.n_contrib; out->accum_coord = img.accum_coord;
     out->accum_depth = img.accum_depth; out->normal_length = img.normal_length;
     if (binning_buffer) {

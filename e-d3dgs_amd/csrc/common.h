@@ -34,7 +34,8 @@ struct GeometryState {
     float *cov3D;          // [P][6]
     uint8_t *clamped;      // [P]
     uint32_t *tiles_touched;
-    uint32_t *point_offsets;   // inclusive scan of tiles_touched in Gaussian order (num_rendered = last element)
+    uint32_t *point_offsets;   // inclusive scan of tiles_touched in Gaussian order: formed on demand (ed3dgs_state_view_get) only
+    uint32_t *block_tiles;     // [ceil(P / 256)] sum of tiles_touched over each preprocess block: the host adds them up (num_rendered)
     char *scan_space;
     size_t scan_size;
     // depth pre-sort (binning level 1): Gaussians ordered by view depth, and the scan of tiles_touched in THAT order

@@ -194,14 +194,17 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size, int *__restrict__ radii,
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
-    uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition)
+    uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition,
+    uint32_t *__restrict__ block_tiles)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
+    const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = idx_raw < P;
+    const int idx = live ? idx_raw : P - 1;
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t out_key = 0xFFFFFFFFu;  // culled Gaussians sort to the end of the depth order (they emit nothing)
     do {
+        if (!live) break;
         v3 p_orig = mk3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
         v3 p_view = xform4x3(p_orig, view);
         if (p_view.z <= 0.2f) break;  // near cull only (Q8)
@@ -265,10 +268,20 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         out_radius = (int)my_radius;
         out_tiles = (uint32_t)((rmax.y - rmin.y) * (rmax.x - rmin.x));
     } while (0);
-    radii[idx] = out_radius;
-    tiles_touched[idx] = out_tiles;
-    depth_keys[idx] = out_key;
-    ids[idx] = (uint32_t)idx;
+    if (live) {
+        radii[idx] = out_radius;
+        tiles_touched[idx] = out_tiles;
+        depth_keys[idx] = out_key;
+        ids[idx] = (uint32_t)idx;
+    }
+    // the block's instance count (the host adds the blocks up: num_rendered, CR/rasterizer_impl.cu:355-359 without the scan)
+    __shared__ uint32_t wave_tiles[4];
+    uint32_t t = out_tiles;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) wave_tiles[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) block_tiles[blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means,
@@ -572,13 +585,14 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
-                           g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition);
+                           g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition,
+                           g.block_tiles);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, (float *)nullptr,
-                           (uint8_t *)nullptr);
+                           (uint8_t *)nullptr, g.block_tiles);
 }
 
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s)

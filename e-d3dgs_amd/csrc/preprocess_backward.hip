@@ -118,7 +118,7 @@ __device__ __forceinline__ void preprocess_backward_body(
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D, float *__restrict__ sh_row,
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
-    if (!(radii[idx] > 0)) {
+    auto write_zeros = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; i++) { dL_dmean2D[3 * idx + i] = 0.f; dL_dcolor[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
         dL_dopacity[idx] = 0.f;
@@ -131,14 +131,27 @@ __device__ __forceinline__ void preprocess_backward_body(
 #pragma unroll
             for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
         }
-        return;
-    }
+    };
+    if (!(radii[idx] > 0)) { write_zeros(); return; }
     // ---- unpack the tile pass' record, apply the per-Gaussian linear post-factors ----
     float gr[GREC];
     {
         const float4 *g4 = reinterpret_cast<const float4 *>(grec + (size_t)idx * GREC);
 #pragma unroll
         for (int i = 0; i < 4; i++) { float4 t = g4[i]; gr[4 * i] = t.x; gr[4 * i + 1] = t.y; gr[4 * i + 2] = t.z; gr[4 * i + 3] = t.w; }
+    }
+    {   // A record the tile pass never added to (the Gaussian is behind the last contributor of every tile it touches: half of a
+        // dense scene): every output is a sum of products with a factor from the record -- exactly zero.  Written as such
+        // without reading the Gaussian's other 400 bytes.
+        bool untouched = true;
+#pragma unroll
+        for (int i = 0; i < GREC; i++) untouched &= gr[i] == 0.f;
+        if (untouched && grec_coord) {
+            const float *gc = grec_coord + (size_t)idx * GREC;
+#pragma unroll
+            for (int i = 0; i < 9; i++) untouched &= gc[i] == 0.f;
+        }
+        if (untouched) { write_zeros(); return; }
     }
     const v3 g_color = mk3(gr[G_R], gr[G_G], gr[G_B]);
     const float dL_dt = gr[G_TS];

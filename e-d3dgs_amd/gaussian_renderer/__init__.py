@@ -44,17 +44,25 @@ def _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifie
     )
 
 
+_ZERO_SCALARS = {}
+
+
+def _zero_scalar(device, dtype):
+    key = (str(device), dtype)
+    z = _ZERO_SCALARS.get(key)
+    if z is None:
+        z = _ZERO_SCALARS[key] = torch.zeros(1, device=device, dtype=dtype)
+    return z
+
+
 def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord, require_depth,
                  override_color, cam_no, iter, num_down_emb_c, num_down_emb_f, disable_filter3D, select):
     """select: None = all Gaussians; +1 = rows with round(tongue_class) != 0 (render_tongue :155,246-253);
     -1 = the complement (render_without_tongue :299,390-397).  Deformation always runs on all P."""
     means3D = pc.get_xyz
-    # zero tensor whose .grad receives the screen-space mean gradients (train.py:346-348 reads it)
-    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # zero tensor whose .grad receives the screen-space mean gradients (train.py:346-348 reads it).  Nothing reads its
+    # values, so it is a fresh leaf over ONE cached zero (expanded view: no fill launch per call; an in-place write raises)
+    screenspace_points = _zero_scalar(means3D.device, means3D.dtype).expand(means3D.shape).requires_grad_()
     raster_settings = _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, require_coord,
                                 require_depth)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)

@@ -121,6 +121,26 @@ class _DeformFn(torch.autograd.Function):
                 g_emb.reshape(sh[4]), *base)
 
 
+class _PackedParams(torch.autograd.Function):
+    """Identity on the packed parameter block; its backward hands each parameter its slice of the packed gradient."""
+
+    @staticmethod
+    def forward(ctx, flat, *parts):
+        ctx.shapes = [p.shape for p in parts]
+        return flat.view(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [], 0
+        for sh in ctx.shapes:
+            n = 1
+            for d in sh:
+                n *= d
+            out.append(g[off:off + n].view(sh))
+            off += n
+        return (None, *out)
+
+
 class deform_network(nn.Module):
     def __init__(self, D=8, W=256, min_embeddings=30, max_embeddings=150, num_frames=300, num_cam=None, args=None):
         super().__init__()
@@ -161,24 +181,43 @@ class deform_network(nn.Module):
         return [p for n, p in self.named_parameters() if n != "offsets"]
 
     # ---- helpers of the fused path ----
-    def _flat_stage(self, s):
-        """The stage's parameters packed as include/ed3dgs.h lays them out.  With autograd on this is a `cat` node (the
-        packed gradient flows back to the modules' parameters); without it (rendering) the packed copy is reused until
-        a parameter changes (torch's per-tensor version counters and storage pointers are the key)."""
+    def _stage_parts(self, s):
         mods = [getattr(self, f"feature_out_{s}")[0]]
         parts = [mods[0].weight, mods[0].bias]
         for h in HEADS:
             seq = getattr(self, f"{h}_deform_{s}")
             parts += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
-        if torch.is_grad_enabled():
-            return torch.cat([p.reshape(-1) for p in parts])
-        key = tuple((p.data_ptr(), p._version) for p in parts)
-        cache = self.__dict__.setdefault("_flat_cache", {})
-        hit = cache.get(s)
-        if hit is None or hit[0] != key:
-            hit = (key, torch.cat([p.detach().reshape(-1) for p in parts]))
-            cache[s] = hit
-        return hit[1]
+        return parts
+
+    def _flat_stage(self, s):
+        """The stage's parameters packed as include/ed3dgs.h lays them out -- WITHOUT a copy per call: the first call (and any
+        call after something re-bound a parameter's storage: .to(), a replaced Parameter) packs them once into one flat buffer
+        and points every parameter's .data at its slice of it, so in-place updates (optimizer steps, load_state_dict) keep the
+        packed block current.  Names, shapes and state-dict contents are untouched.  With autograd on, a view node routes the
+        packed gradient back to the parameters as slices (no copies either way)."""
+        parts = self._stage_parts(s)
+        store = self.__dict__.setdefault("_flat_store", {})
+        flat = store.get(s)
+        ok = flat is not None
+        if ok:
+            off, base = 0, flat.data_ptr()
+            for p in parts:
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or not p.is_contiguous():
+                    ok = False
+                    break
+                off += p.numel()
+            ok = ok and off == flat.numel()
+        if not ok:
+            with torch.no_grad():
+                flat = torch.cat([p.detach().reshape(-1).float() for p in parts])
+                off = 0
+                for p in parts:
+                    p.data = flat[off:off + p.numel()].view(p.shape)
+                    off += p.numel()
+            store[s] = flat
+        if torch.is_grad_enabled() and any(p.requires_grad for p in parts):
+            return _PackedParams.apply(flat, *parts)
+        return flat
 
     def _row_counts(self, it, num_down_emb_c, num_down_emb_f):
         """query_time (:72-80)"""
