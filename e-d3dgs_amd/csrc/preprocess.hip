@@ -200,6 +200,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = idx_raw < P;
     const int idx = live ? idx_raw : P - 1;
+    // (Tried in round 2: the block's SH rows fetched as one coalesced stream into LDS and read from there -- 53 us instead of
+    // 41 us at 200k: 50 KB of LDS per block halves the resident waves, and this kernel lives on latency hiding, not on the
+    // load instructions' efficiency.)
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t out_key = 0xFFFFFFFFu;  // culled Gaussians sort to the end of the depth order (they emit nothing)
@@ -330,9 +333,10 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(int P, const f
 //                       start inside the tile's list, and the tile's total
 //   bin_tiles_kernel    one block: exclusive scan of the totals -> ranges (untouched tiles stay (0, 0), as K5 leaves them),
 //                       and the tile order of the tile kernels (longest list first)
-//   bin_scatter_kernel  block b (one wave) walks its 256 rows IN ORDER; a row's tiles are distinct, so lane = tile of the row:
-//                       position = the tile's cursor in LDS, cursor + 1 -- rows of a block stay in depth order inside every
-//                       tile, blocks are ordered by the column scan: the permutation is the stable sort's, ties included.
+//   bin_scatter_kernel  block b: wave w walks rows 64 w .. 64 w + 63 IN ORDER; a row's tiles are distinct, so lane = tile of the
+//                       row: position = the block's start in the tile + the wave's running rank (see the kernel) -- rows of a
+//                       block stay in depth order inside every tile, blocks are ordered by the column scan: the permutation is
+//                       the stable sort's, ties included.
 // 4 launches and ~25 MB of counter traffic at 200k / 1080p instead of 19 launches (two 8-byte-pair radix passes over 3.3 M
 // instances with their histogram / look-back memsets, a scan, a memset, K3, K5, the order sort).
 // ------------------------------------------------------------------------------------------------------------
@@ -445,72 +449,108 @@ __global__ void __launch_bounds__(1024) bin_tiles_kernel(int T, const uint32_t *
 __global__ void __launch_bounds__(256) bin_scatter_kernel(int P, int T, const float *__restrict__ rec, const uint32_t *__restrict__ order,
                                                          const int *__restrict__ radii, int gx, int gy, const uint32_t *__restrict__ C,
                                                          const uint2 *__restrict__ ranges, uint32_t *__restrict__ tile_keys,
-                                                         uint32_t *__restrict__ point_list)
+                                                         uint32_t *__restrict__ point_list, unsigned long long *__restrict__ timing)
 {
-    extern __shared__ uint32_t bin_lds[];   // the tiles' cursors: where this block's next instance of tile t goes
-    // four waves: all walk the block's rows in order, wave w places the instances of the tiles t with (t & 3) == w -- a tile's
-    // instances stay in one wave, so their order is the rows' (one wave's LDS atomics complete in order)
+    // cur[t]: where this block's first instance of tile t goes.  word[t]: four byte fields, one per wave.
+    // Wave w owns rows 64 w .. 64 w + 63 of the block.  Pass 1 counts each wave's instances per tile into its field (<= 64;
+    // additions commute, so a thread per row with a loop over its rect will do); the fields are then turned into exclusive
+    // prefixes over the waves (<= 192: a byte); pass 2 walks the wave's rows IN ORDER, lane = tile of the row (a row's tiles are
+    // distinct, and one wave's LDS atomics complete in order), and an instance's position is cur + the old value of the wave's
+    // field, which the same atomic advances.  Other waves only ever add to their own fields (no carries: field w ends at field
+    // w + 1's start; the top field may wrap to 256 after its last read).  Rows of a block stay in depth order inside every
+    // tile, blocks are ordered by the column scan: the permutation is the stable sort's, ties included.
+    // (Round 2's first form had every wave walk all 256 rows for a quarter of the tiles: four lanes busy per row.)
+    extern __shared__ uint32_t bin_lds[];
+    uint32_t *cur = bin_lds, *word = bin_lds + T;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t *row = C + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += 256) bin_lds[t] = ranges[t].x + row[t];
+    const bool timed = timing != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;   // diagnostic (ED3DGS_BIN_TIMING)
+    unsigned long long tq[6];
+    if (timed) tq[0] = clock64();
+    // 16 loads in flight per thread: element by element this loop is 32 dependent HBM round trips, most of the kernel's time
+    for (int t0 = threadIdx.x; t0 < T; t0 += 256 * 8) {
+        uint32_t a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int t = min(t0 + 256 * q, T - 1);
+            a[q] = ranges[t].x; b[q] = row[t];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int t = t0 + 256 * q;
+            if (t < T) { cur[t] = a[q] + b[q]; word[t] = 0u; }
+        }
+    }
+    const int i = blockIdx.x * BIN_ROWS + wv * 64 + lane;
+    uint32_t idx = 0;
+    int x0 = 0, y0 = 0, w = 0, n = 0, hgt = 0;
+    if (i < P) {
+        idx = order[i];
+        const int rad = radii[idx];
+        if (rad > 0) {
+            const float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
+            int2 rmin, rmax;
+            get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
+            x0 = rmin.x; y0 = rmin.y; w = rmax.x - rmin.x; hgt = rmax.y - rmin.y; n = w * hgt;
+        }
+    }
+    const uint32_t one = 1u << (8 * wv);
     __syncthreads();
-    for (int i0 = 0; i0 < BIN_ROWS; i0 += 64) {
-        // 64 rows' data, one per lane; then the rows one after the other, the wave's lanes on the row's tiles
-        const int i = blockIdx.x * BIN_ROWS + i0 + lane;
-        uint32_t idx = 0;
-        int x0 = 0, y0 = 0, w = 0, n = 0;
-        if (i < P) {
-            idx = order[i];
-            const int rad = radii[idx];
-            if (rad > 0) {
-                const float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
-                int2 rmin, rmax;
-                get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
-                x0 = rmin.x; y0 = rmin.y; w = rmax.x - rmin.x; n = w * (rmax.y - rmin.y);
+    if (timed) tq[1] = clock64();
+    for (int y = 0; y < hgt; y++)
+        for (int x = 0; x < w; x++) atomicAdd(&word[(y0 + y) * gx + x0 + x], one);
+    __syncthreads();
+    if (timed) tq[2] = clock64();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const uint32_t v = word[t], c0 = v & 255u, c1 = (v >> 8) & 255u, c2 = (v >> 16) & 255u;
+        word[t] = (c0 << 8) | ((c0 + c1) << 16) | ((c0 + c1 + c2) << 24);
+    }
+    __syncthreads();
+    if (timed) tq[3] = clock64();
+    unsigned long long live = __ballot(n > 0);
+    const int sh = 8 * wv;
+    // four rows at a time: their LDS atomics go out back to back (one wave's LDS operations complete in order, so two rows
+    // that share a tile still get consecutive positions in row order) and the stores follow
+    while (live) {
+        uint32_t ridx[4], tile[4], pos[4];
+        bool act[4];
+        int big = -1;                       // a rect of more than 64 tiles ends the group: it runs after the rows before it
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            act[q] = false; tile[q] = 0; ridx[q] = 0;
+            if (live && big < 0) {
+                const int j = __builtin_ctzll(live);
+                live &= live - 1;
+                const int rn = __builtin_amdgcn_readlane(n, j);
+                if (rn > 64) { big = j; continue; }
+                ridx[q] = (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
+                const int rx0 = __builtin_amdgcn_readlane(x0, j), ry0 = __builtin_amdgcn_readlane(y0, j);
+                const int rw = __builtin_amdgcn_readlane(w, j);
+                // lane = position inside the rect, row-major as K3 emits; small exact division in floating point
+                const int ty = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)rw)), tx = lane - ty * rw;
+                tile[q] = (uint32_t)((ry0 + ty) * gx + rx0 + tx);
+                act[q] = lane < rn;
             }
         }
-        unsigned long long live = __ballot(n > 0);
-        // four rows at a time: their LDS atomics go out back to back (one wave's LDS operations complete in order, so two rows
-        // that share a tile still get consecutive positions in row order) and the stores follow
-        while (live) {
-            uint32_t ridx[4], tile[4], pos[4];
-            bool act[4];
-            int big = -1;                       // a rect of more than 64 tiles ends the group: it runs after the rows before it
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                act[q] = false; tile[q] = 0; ridx[q] = 0;
-                if (live && big < 0) {
-                    const int j = __builtin_ctzll(live);
-                    live &= live - 1;
-                    const int rn = __builtin_amdgcn_readlane(n, j);
-                    if (rn > 64) { big = j; continue; }
-                    ridx[q] = (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
-                    const int rx0 = __builtin_amdgcn_readlane(x0, j), ry0 = __builtin_amdgcn_readlane(y0, j);
-                    const int rw = __builtin_amdgcn_readlane(w, j);
-                    // lane = position inside the rect, row-major as K3 emits; small exact division in floating point
-                    const int ty = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)rw)), tx = lane - ty * rw;
-                    tile[q] = (uint32_t)((ry0 + ty) * gx + rx0 + tx);
-                    act[q] = lane < rn && (int)(tile[q] & 3u) == wv;
-                }
-            }
+        for (int q = 0; q < 4; q++) pos[q] = act[q] ? cur[tile[q]] + ((atomicAdd(&word[tile[q]], one) >> sh) & 255u) : 0u;
 #pragma unroll
-            for (int q = 0; q < 4; q++) pos[q] = act[q] ? atomicAdd(&bin_lds[tile[q]], 1u) : 0u;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (act[q]) point_list[pos[q]] = ridx[q];
-            if (big >= 0) {
-                const uint32_t bidx = (uint32_t)__builtin_amdgcn_readlane((int)idx, big);
-                const int rx0 = __builtin_amdgcn_readlane(x0, big), ry0 = __builtin_amdgcn_readlane(y0, big);
-                const int rw = __builtin_amdgcn_readlane(w, big), rn = __builtin_amdgcn_readlane(n, big);
-                for (int e = lane; e < rn; e += 64) {
-                    const int ty = e / rw, tx = e - ty * rw;
-                    const uint32_t tl = (uint32_t)((ry0 + ty) * gx + rx0 + tx);
-                    if ((int)(tl & 3u) != wv) continue;
-                    const uint32_t ps = atomicAdd(&bin_lds[tl], 1u);
-                    point_list[ps] = bidx;
-                }
+        for (int q = 0; q < 4; q++)
+            if (act[q]) point_list[pos[q]] = ridx[q];
+        if (big >= 0) {
+            const uint32_t bidx = (uint32_t)__builtin_amdgcn_readlane((int)idx, big);
+            const int rx0 = __builtin_amdgcn_readlane(x0, big), ry0 = __builtin_amdgcn_readlane(y0, big);
+            const int rw = __builtin_amdgcn_readlane(w, big), rn = __builtin_amdgcn_readlane(n, big);
+            for (int e = lane; e < rn; e += 64) {
+                const int ty = e / rw, tx = e - ty * rw;
+                const uint32_t tl = (uint32_t)((ry0 + ty) * gx + rx0 + tx);
+                point_list[cur[tl] + ((atomicAdd(&word[tl], one) >> sh) & 255u)] = bidx;
             }
         }
+    }
+    if (timed) {
+        tq[4] = clock64();
+        for (int q = 0; q < 4; q++) timing[q] = tq[q + 1] - tq[q];
     }
 }
 
@@ -629,8 +669,19 @@ void launch_bin_transpose(int P, int W, int H, const GeometryState &g, const int
     hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(256), lds, s, P, T, g.rec, g.order, radii, gx, gy, C);
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64), 0, s, B, T, C, total);   // one wave per block: 128 CUs busy instead of 32
     hipLaunchKernelGGL(bin_tiles_kernel, dim3(1), dim3(1024), 0, s, T, total, reinterpret_cast<uint2 *>(ranges), tile_order);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(256), lds, s, P, T, g.rec, g.order, radii, gx, gy, C,
-                       reinterpret_cast<const uint2 *>(ranges), tile_keys, point_list);
+    static unsigned long long *bin_timing_buf = nullptr;
+    if (getenv("ED3DGS_BIN_TIMING") && !bin_timing_buf) (void)hipMalloc((void **)&bin_timing_buf, 8 * sizeof(unsigned long long));
+    unsigned long long *bin_timing = getenv("ED3DGS_BIN_TIMING") ? bin_timing_buf : nullptr;
+    // cursors + the per-wave rank fields: 2 T words (65 KB at 1080p); above the default 64 KB the limit has to be raised
+    if (2 * lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(256), 2 * lds, s, P, T, g.rec, g.order, radii, gx, gy, C,
+                       reinterpret_cast<const uint2 *>(ranges), tile_keys, point_list, bin_timing);
+    if (bin_timing) {   // diagnostic: cycles of the middle block's wave 0 in (cursors, count pass, prefixes, scatter pass)
+        unsigned long long t[4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(t, bin_timing, sizeof t, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[ed3dgs] bin_scatter cycles: cursors %llu count %llu prefixes %llu scatter %llu\n", t[0], t[1], t[2], t[3]);
+    }
 }
 
 void launch_tile_order(int T, const uint32_t *ranges, uint32_t *tile_order, hipStream_t s)
