@@ -105,6 +105,8 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
         inflight.append(D.allreduce_sum_async(stats))
         if dp_grads:             # opt-in: data-parallel training, mean of the ranks' gradients
             D.allreduce_gradients_(params)
+        if step.probe is not None:   # untimed passes only: look at the gradients before they are dropped
+            step.probe(model)
         for p in params:
             p.grad = None
         pkg["viewspace_points"].grad = None
@@ -116,6 +118,7 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
 
     step.drain = drain
     step.n = 0
+    step.probe = None
     return step
 
 
@@ -366,8 +369,13 @@ def main():
     # K7's work counts (visited iterations, blended pairs, ...): a short pass of its own -- counting slows the kernel down
     n_count = min(4, a.steps)
     L.ed3dgs_profile_begin_slots(ctypes.c_int(n_count + 2), ctypes.c_uint(2 | (1 << 30)))
+    # ... and the rows the deformation backward walks: Gaussians with a non-zero upstream gradient = non-zero dL/d embedding rows
+    active_rows = []
+    if wl.get("deform", True):
+        step.probe = lambda m: active_rows.append(int((m._embedding.grad.abs().amax(dim=1) > 0).sum()))
     for k in range(n_count):
         step(item_at(k))
+    step.probe = None
     step.drain()
     torch.cuda.synchronize()
     cnt_ms, cnt_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
@@ -492,7 +500,11 @@ def main():
         6: ({"exact_split": "deform_head_wgrad_tr_kernel<true>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false,true>"}[mode], mac_wide, {"exact_split": 8, "bf16x3": 3, "fp32_mfma": 1}[mode]),
         7: ({"exact_split": "deform_head_wgrad_tr_kernel<false>", "bf16x3": "deform_head_wgrad_kernel<false,true,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false,true>"}[mode], mac_narrow, npr),
     }
-    tfl = lambda mac, ms: 2.0 * mac * wl["P"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    tfl = lambda mac, ms, rows=None: 2.0 * mac * (wl["P"] if rows is None else rows) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # the backward kernels walk only the rows with a non-zero upstream gradient (csrc/deform.hip, deform_active_rows_body):
+    # their rates are priced on the rows they process, not on P
+    dense_bwd = bool(os.environ.get("ED3DGS_DEFORM_DENSE_BWD")) or mode != "exact_split"
+    rows_bwd = wl["P"] if (dense_bwd or not active_rows) else mean(active_rows)
     kernels = {
         "_source": "separate instrumented pass of the same %d steps (event pairs around every kernel), not the timed region" % a.steps,
         "_mode": mode,
@@ -501,8 +513,9 @@ def main():
     }
     if dm:
         for sl, (nm, mac, pr) in K.items():
-            kernels[nm] = {"avg_launch_ms": tab_avg[sl], "launches": tab_n[sl], "bound": "mfma",
-                           "TFLOPs_fp32_equivalent": tfl(mac, tab_avg[sl]),
+            rows = wl["P"] if sl == 2 else rows_bwd
+            kernels[nm] = {"avg_launch_ms": tab_avg[sl], "launches": tab_n[sl], "bound": "mfma", "rows_per_launch": rows,
+                           "TFLOPs_fp32_equivalent": tfl(mac, tab_avg[sl], rows),
                            "matrix_pipe": "bf16 (%d exact piece products per multiply)" % pr if pr > 1 else "f32"}
         kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
     # K7 against the vector-ALU roof: its inner loop issues K7_VALU_PER_ITER vector instructions per visited (tile, Gaussian)
@@ -529,11 +542,12 @@ def main():
                        "reported as defined there, next to the pair rate"}
     if dom >= 2 and dm:
         nm, mac, pr = K[dom]
-        eq = tfl(mac, avg_ms[dom])
+        rows_dom = wl["P"] if dom == 2 else rows_bwd
+        eq = tfl(mac, avg_ms[dom], rows_dom)
         peak = MFMA_BF16_PEAK_TFLOPS if pr > 1 else MFMA_F32_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": nm, "achieved": eq * pr, "peak": peak, "unit": "TFLOP/s", "frac": eq * pr / peak,
                 "traffic": pmc.get(nm.split(" ")[0]), "traffic_source": traffic_source,
-                "algorithmic_flops_per_launch": 2.0 * mac * wl["P"], "executed_matrix_flops_per_launch": 2.0 * mac * wl["P"] * pr,
+                "algorithmic_flops_per_launch": 2.0 * mac * rows_dom, "executed_matrix_flops_per_launch": 2.0 * mac * rows_dom * pr,
                 "fp32_equivalent_TFLOPs": eq, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
                 "note": ("dominant kernel of the step by time.  Algorithmic flops = 2 * %d MAC per Gaussian (fp32 multiplies); " % mac) +
                         ("each fp32 multiply runs as %d exact bf16 piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, "
@@ -559,6 +573,11 @@ def main():
                    "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
         "render_fps": world * a.steps / dt_r,
         "render_fps_note": "forward only, all outputs (coord+depth+normal), torch.no_grad, incl. deformation",
+        "deform_backward_rows": {"active_mean": (mean(active_rows) if active_rows else None), "of": wl["P"],
+                                 "walked": rows_bwd,
+                                 "note": "Gaussians with a non-zero upstream gradient in the counted items (the rest are culled or "
+                                         "behind the last contributor of every tile they touch: exact zeros); the default backward "
+                                         "walks only these rows -- results identical to the dense walk (ED3DGS_DEFORM_DENSE_BWD=1)"},
         "roofline": roof,
         "roofline_tile_backward": roof_k7,
         "kernels": kernels,

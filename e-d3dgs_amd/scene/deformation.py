@@ -17,6 +17,9 @@ from ed3dgs_amd import _lib
 HEADS = ("pos", "scales", "rotations", "opacity", "rgb")
 # False: the backward re-forms the activations from the inputs (stateless C-ABI backward; less memory, more MFMA work)
 KEEP_ACTIVATIONS = True
+# True: the kept activations are released by the first backward (a second backward over a retained graph takes the stateless
+# path).  False: they stay with the graph, and every backward over it reads them again.
+RELEASE_KEPT_WORKSPACE = True
 
 
 def _ptr(t):
@@ -94,7 +97,8 @@ class _DeformFn(torch.autograd.Function):
         ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1))
         kept = ctx.kept_ws is not None
         ws = ctx.kept_ws if kept else torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        ctx.kept_ws = None
+        if RELEASE_KEPT_WORKSPACE:
+            ctx.kept_ws = None   # 6 KB per Gaussian go back to the allocator; a second backward (retain_graph) re-forms the activations
         params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
         gparams = (C.c_void_p * 2)(gfc.data_ptr() if cfgd["use_stage"][0] else None, gff.data_ptr() if cfgd["use_stage"][1] else None)
         rc = L.ed3dgs_deform_backward(

@@ -263,6 +263,41 @@ def test_split_sh_storage_matches_whole(P, flags, loss_on_sub, monkeypatch):
         assert float((p1[n] - p2[n]).abs().max()) <= 1e-5 * max(float(p1[n].abs().max()), 1e-30), n
 
 
+@pytest.mark.parametrize("release", [False, True], ids=["workspace-kept", "workspace-released"])
+def test_second_backward_over_a_retained_graph(release, monkeypatch):
+    """retain_graph=True and a second backward.  Workspace kept with the graph: the active-row counters in it were re-armed
+    by the first backward's last block, so the second walk sees the same rows -- dL/d inputs exactly double (they are
+    deterministic), the weight gradients double up to the order of their atomic sums.  Workspace released by the first
+    backward (the default): the second one re-forms the activations (stateless kernels) -- double within the tolerance."""
+    _need_gpu()
+    from oracle import deformation_ref as R
+    import scene.deformation as SD
+    from scene.deformation import deform_network
+    monkeypatch.setattr(SD, "RELEASE_KEPT_WORKSPACE", release)
+    a = R.Args(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000)
+    torch.manual_seed(21)
+    net = deform_network(D=1, W=128, min_embeddings=30, max_embeddings=150, num_frames=300, args=a).cuda()
+    g = torch.Generator().manual_seed(22)
+    P = 9001
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda().requires_grad_(True)
+    xyz, sc_, rot, op, sh, emb = mk(P, 3), mk(P, 3, sc=0.3), mk(P, 4), mk(P, 1), mk(P, 16, 3, sc=0.5), mk(P, 32, sc=0.1)
+    outs = net(xyz, sc_, rot, op, 0.61, None, _PC(emb), None, sh, iter=20000, num_down_emb_c=30, num_down_emb_f=30)
+    w = (torch.rand(P, generator=g) < 0.4).float().cuda()
+    loss = sum((x.reshape(P, -1) * w[:, None]).sum() for x in outs[:5])
+    loss.backward(retain_graph=True)
+    e1 = emb.grad.clone()
+    p1 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    assert float(e1[w == 0].abs().max()) == 0.0 and float(e1[w > 0].abs().max()) > 0
+    loss.backward()
+    if release:
+        assert float((emb.grad - 2 * e1).abs().max()) <= TOL * float(e1.abs().max())
+    else:
+        assert torch.equal(emb.grad, 2 * e1)
+    for n, p in net.named_parameters():
+        if n in p1 and float(p1[n].abs().max()) > 0:
+            assert float((p.grad - 2 * p1[n]).abs().max()) <= (TOL if release else 1e-5) * float(p1[n].abs().max()), n
+
+
 @pytest.mark.parametrize("with_filter", [False, True])
 def test_fused_activations_match_torch(with_filter):
     """a7 (scene/gaussian_model.py:37-45, 594-603): the fused HIP activation kernel against the torch ops the
