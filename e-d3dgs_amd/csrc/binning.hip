@@ -50,6 +50,9 @@ bool run_scan_gather(char *temp, size_t temp_bytes, const uint32_t *in, const ui
     return check_hip(hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, it, out, P, s), "InclusiveSum (depth order)");
 }
 
+// (Level 1, 200k keys: below a million items the library runs a merge sort behind this entry point -- 9 launches, 60 us.
+// Forcing its Onesweep radix sort instead (rocprim::radix_sort_config<..., MergeSortLimit = 0>) was measured in round 2:
+// 15 launches with its look-back memsets, 155 us.  The library's choice stands.)
 bool run_sort(char *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
               int n, int end_bit, hipStream_t s)
 {
