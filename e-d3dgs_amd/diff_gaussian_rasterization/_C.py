@@ -57,7 +57,7 @@ class _Grow:
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.raw_stream(torch.device("cuda", torch.cuda.current_device()))
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scales, rotations, scale_modifier,

@@ -25,7 +25,7 @@ class _Activations(torch.autograd.Function):
         P = s.shape[0]
         so, ro, oo = torch.empty_like(s), torch.empty_like(r), torch.empty_like(o)
         rc = L.ed3dgs_activations_forward(C.c_int(P), _p(s), _p(r), _p(o), _p(f), _p(so), _p(ro), _p(oo),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                          _lib.raw_stream(s.device))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         ctx.save_for_backward(s, r, o, *( [f] if f is not None else [] ))
@@ -42,7 +42,7 @@ class _Activations(torch.autograd.Function):
         gs, gr, go = c(gs), c(gr), c(go)
         gsl, grr, gol = torch.empty_like(s), torch.empty_like(r), torch.empty_like(o)
         rc = L.ed3dgs_activations_backward(C.c_int(s.shape[0]), _p(s), _p(r), _p(o), _p(f), _p(gs), _p(gr), _p(go),
-                                           _p(gsl), _p(grr), _p(gol), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                           _p(gsl), _p(grr), _p(gol), _lib.raw_stream(s.device))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         return gsl, grr, gol, None

@@ -59,7 +59,7 @@ class _DeformFn(torch.autograd.Function):
         rc = L.ed3dgs_deform_forward(
             C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
             _ptr(sh_), _ptr(shr_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
-            C.c_int(1 if keep else 0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            C.c_int(1 if keep else 0), _lib.raw_stream(dev))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         ctx.kept_ws = ws if rc == 1 else None
@@ -104,7 +104,7 @@ class _DeformFn(torch.autograd.Function):
         rc = L.ed3dgs_deform_backward(
             C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), *[_ptr(g) for g in g_out],
             *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(g_dc), _ptr(g_rest), _ptr(ws),
-            C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), _lib.raw_stream(dev))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         if not cfgd["use_stage"][0]:
@@ -186,11 +186,27 @@ class deform_network(nn.Module):
 
     # ---- helpers of the fused path ----
     def _stage_parts(self, s):
-        mods = [getattr(self, f"feature_out_{s}")[0]]
-        parts = [mods[0].weight, mods[0].bias]
-        for h in HEADS:
-            seq = getattr(self, f"{h}_deform_{s}")
-            parts += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
+        """The stage's 22 parameters in packed order.  The Linear modules are looked up once (nn.Sequential indexing is slow)
+        and re-checked by identity against the module tree on every call; their parameters are read from the modules on every
+        call, so a replaced module or Parameter is seen."""
+        cache = self.__dict__.setdefault("_stage_linears", {})
+        ent = cache.get(s)
+        mods = self._modules
+        if ent is not None:
+            for name, idx, seq, lin in ent:
+                if mods[name] is not seq or seq._modules[idx] is not lin:
+                    ent = None
+                    break
+        if ent is None:
+            ent = [(f"feature_out_{s}", "0", mods[f"feature_out_{s}"], mods[f"feature_out_{s}"][0])]
+            for h in HEADS:
+                seq = mods[f"{h}_deform_{s}"]
+                ent += [(f"{h}_deform_{s}", "1", seq, seq[1]), (f"{h}_deform_{s}", "3", seq, seq[3])]
+            cache[s] = ent
+        parts = []
+        for _, _, _, m in ent:
+            pr = m._parameters
+            parts.append(pr["weight"]); parts.append(pr["bias"])
         return parts
 
     def _flat_stage(self, s):
