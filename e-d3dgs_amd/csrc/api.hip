@@ -163,8 +163,8 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5
-    const size_t tr_bytes = getenv("ED3DGS_BIN_RADIX") ? 0 : bin_transpose_bytes(P, (int)T);
-    if (!tr_bytes) {
+    const bool transpose = !getenv("ED3DGS_BIN_RADIX") && bin_transpose_bytes(P, width, height, 0) > 0;
+    if (!transpose) {
         if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
         if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
     }
@@ -176,13 +176,15 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     const int R = (int)num_rendered_u;
 
     // (the transpose's counters ride at the END of the binning buffer: the backward carves the same layout from R alone)
+    const size_t tr_bytes = transpose ? bin_transpose_bytes(P, width, height, R) : 0;
     char *bin_chunk = binning_alloc(binning_user, ed3dgs_binning_bytes(R) + tr_bytes);
     if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
     char *bin_end = bin_chunk;
     bin = BinningState::from_chunk(bin_end, R);
 
     if (tr_bytes) {
-        launch_bin_transpose(P, width, height, geom, radii, bin_end, img.ranges, img.tile_order, bin.tile_keys, bin.point_list, s);
+        launch_bin_transpose(P, width, height, R, geom, radii, bin_end, img.ranges, img.tile_order, bin.tile_keys, bin.point_list,
+                             bin.point_list_unsorted, bin.tile_keys_unsorted, s);
         if (!ok("binTranspose")) return ED3DGS_ERR_HIP;
         return R;
     }

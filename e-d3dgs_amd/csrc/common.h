@@ -86,9 +86,10 @@ void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii,
                                 uint32_t *values, hipStream_t s);
 void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ranges, hipStream_t s);
 void launch_tile_order(int T, const uint32_t *ranges, uint32_t *tile_order, hipStream_t s);
-size_t bin_transpose_bytes(int P, int T);
-void launch_bin_transpose(int P, int W, int H, const GeometryState &g, const int *radii, char *scratch, uint32_t *ranges,
-                          uint32_t *tile_order, uint32_t *tile_keys, uint32_t *point_list, hipStream_t s);
+size_t bin_transpose_bytes(int P, int W, int H, int R);
+void launch_bin_transpose(int P, int W, int H, int R, const GeometryState &g, const int *radii, char *scratch, uint32_t *ranges,
+                          uint32_t *tile_order, uint32_t *tile_keys, uint32_t *point_list, uint32_t *spare_a, uint32_t *spare_b,
+                          hipStream_t s);
 void launch_compose_keys(int T, const uint32_t *ranges, const uint32_t *point_list, const float *depths,
                          uint64_t *keys, hipStream_t s);
 size_t scan_temp_bytes(int P);

@@ -554,6 +554,325 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(int P, int T, const fl
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The transpose in TWO LEVELS (round 2, second half).  The one-level scatter above is bound by its stores: a block of 256 rows
+// writes ~1.3 consecutive entries per tile it touches, 3.3 M scattered 4-byte stores that cost 0.17 GB of HBM traffic for 13 MB of
+// list (PMC).  Longer runs need fewer, larger columns first:
+//   level A: rows -> SUPER-TILES of 8 x 8 tiles (135 at 1080p).  The same stable transpose (count per block of 1024 rows, column
+//            scan, scatter in row order), but a row has ~1.7 super-tiles instead of ~16 tiles, the counters are 135 words, and an
+//            entry carries what level B needs: the Gaussian id and its tile rect (4 x 8 bits).
+//   level B: a block takes a segment of <= 1024 consecutive entries of one super-tile (in depth order).  An entry's tiles inside
+//            the super-tile are a 64-bit mask; for tile t, ballot(bit t) over a wave's 64 entries ranks them, so a tile's
+//            entries leave as ONE run of consecutive addresses per wave and tile.  Counts first (bin2_count_kernel: per segment
+//            and tile, and the tile totals by atomics), ranges and the tile order from the totals (bin_tiles_kernel, as before),
+//            then the writes (bin2_write_kernel).
+// Order: level A keeps rows in depth order inside a super-tile; segments, wave chunks and lanes are walked in that order in
+// level B: the permutation is the stable sort's, ties included (bit-identical lists, ranges and keys: the same parity tests).
+// 6 launches; needs tile coordinates below 256 (images up to 4080 px) and at most 1024 super-tiles, else the one-level form runs.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ST_SHIFT = 3;          // super-tile = 8 x 8 tiles: one 64-bit mask
+constexpr int A_ROWS = 1024;         // rows per level-A block: 16 waves of 64 rows
+constexpr int B_SEG = 256;           // super-tile entries per level-B segment (one block iteration): a wave owns 64
+
+struct Bin2 {
+    uint32_t *CA;        // [BA][S] per-block super-tile counts, then their exclusive column prefixes
+    uint32_t *rangesA;   // [S + 1] super-tile list starts (rangesA[S] = number of entries)
+    uint32_t *segstart;  // [S + 1] first level-B block of each super-tile
+    uint32_t *cntB;      // [maxseg][64] per-segment tile counts
+    uint32_t *total;     // [T] tile totals
+    uint32_t *la_idx, *la_rect;   // level-A lists: Gaussian id, packed tile rect x0 | y0 << 8 | x1 << 16 | y1 << 24 (exclusive ends)
+    int BA, S, sgx, sgy, maxseg;
+};
+
+__device__ __forceinline__ bool bin2_row(int i, int P, const float *__restrict__ rec, const uint32_t *__restrict__ order,
+                                         const int *__restrict__ radii, int gx, int gy, uint32_t &idx, int2 &rmin, int2 &rmax)
+{
+    if (i >= P) return false;
+    idx = order[i];
+    const int rad = radii[idx];
+    if (!(rad > 0)) return false;
+    const float2 xy = *reinterpret_cast<const float2 *>(rec + (size_t)idx * REC);
+    get_rect(xy.x, xy.y, rad, gx, gy, rmin, rmax);
+    return (rmax.x - rmin.x) * (rmax.y - rmin.y) > 0;
+}
+
+__global__ void __launch_bounds__(1024) bin2_countA_kernel(int P, int T, const float *__restrict__ rec, const uint32_t *__restrict__ order,
+                                                           const int *__restrict__ radii, int gx, int gy, Bin2 b)
+{
+    extern __shared__ uint32_t bin_lds[];
+    for (int s = threadIdx.x; s < b.S; s += 1024) bin_lds[s] = 0;
+    for (int t = blockIdx.x * 1024 + threadIdx.x; t < T; t += gridDim.x * 1024) b.total[t] = 0;   // level B adds into these
+    __syncthreads();
+    uint32_t idx;
+    int2 rmin, rmax;
+    if (bin2_row(blockIdx.x * A_ROWS + threadIdx.x, P, rec, order, radii, gx, gy, idx, rmin, rmax)) {
+        const int sx0 = rmin.x >> ST_SHIFT, sx1 = (rmax.x - 1) >> ST_SHIFT, sy0 = rmin.y >> ST_SHIFT, sy1 = (rmax.y - 1) >> ST_SHIFT;
+        for (int y = sy0; y <= sy1; y++)
+            for (int x = sx0; x <= sx1; x++) atomicAdd(&bin_lds[y * b.sgx + x], 1u);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < b.S; s += 1024) b.CA[(size_t)blockIdx.x * b.S + s] = bin_lds[s];
+}
+
+// 64 x 64 bit matrix across a wave: lane i gives row i, lane t gets column t (bit i of the result = bit t of lane i's row).
+// Six butterfly steps (blocks of 32, 16, .. 1): a lane keeps its diagonal block and swaps the other with its partner.
+__device__ __forceinline__ unsigned long long wave_transpose64(unsigned long long x, int lane)
+{
+    const unsigned long long MK[6] = {0xFFFFFFFF00000000ull, 0xFFFF0000FFFF0000ull, 0xFF00FF00FF00FF00ull,
+                                      0xF0F0F0F0F0F0F0F0ull, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull};
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const int k = 32 >> q;
+        const uint32_t plo = __shfl_xor((uint32_t)x, k), phi = __shfl_xor((uint32_t)(x >> 32), k);
+        const unsigned long long p = ((unsigned long long)phi << 32) | plo;
+        x = (lane & k) ? ((x & MK[q]) | ((p >> k) & ~MK[q])) : ((x & ~MK[q]) | ((p << k) & MK[q]));
+    }
+    return x;
+}
+
+__global__ void __launch_bounds__(1024) bin2_scatterA_kernel(int P, const float *__restrict__ rec, const uint32_t *__restrict__ order,
+                                                             const int *__restrict__ radii, int gx, int gy, Bin2 b,
+                                                             unsigned long long *__restrict__ timing)
+{
+    const bool timed = timing != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;   // diagnostic (ED3DGS_BIN_TIMING)
+    unsigned long long tq[8];
+    if (timed) tq[0] = clock64();
+    // cur[s]: where this block's first entry of super-tile s goes; wcnt[w][s]: wave w's entries of super-tile s, then the entries
+    // of the lower waves; tot / scn: the column sums and their scan.
+    // The column scan over the level-A blocks is done HERE, by every block for itself (the count matrix is 100 KB: 7 threads
+    // per column, 28 loads each, all in flight) -- a launch of its own for it was one block's chain of loads, 10 us.
+    // Ranks come from a bit-matrix transpose, not from atomics (see the passes below).
+    extern __shared__ uint32_t bin_lds[];
+    const int S = b.S;
+    uint32_t *cur = bin_lds, *tot = bin_lds + S, *wcnt = bin_lds + 2 * S, *scn = bin_lds + 18 * S;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < 18 * S; q += 1024) bin_lds[q] = 0u;
+    __syncthreads();
+    {
+        const int NP = max(1, 1024 / S);                      // threads per column
+        const int sc = (int)threadIdx.x % S, part = (int)threadIdx.x / S;
+        if (part < NP) {
+            uint32_t pre = 0, all = 0;
+            int r = part;
+            for (; r + 7 * NP < b.BA; r += 8 * NP) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = b.CA[(size_t)(r + k * NP) * S + sc];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { all += v[k]; pre += (r + k * NP < (int)blockIdx.x) ? v[k] : 0u; }
+            }
+            for (; r < b.BA; r += NP) { const uint32_t v = b.CA[(size_t)r * S + sc]; all += v; pre += (r < (int)blockIdx.x) ? v : 0u; }
+            atomicAdd(&cur[sc], pre); atomicAdd(&tot[sc], all);
+        }
+    }
+    if (timed) tq[1] = clock64();
+    // this thread's row
+    uint32_t idx = 0;
+    int2 rmin = {0, 0}, rmax = {0, 0};
+    const bool liverow = bin2_row(blockIdx.x * A_ROWS + threadIdx.x, P, rec, order, radii, gx, gy, idx, rmin, rmax);
+    int sx0 = 1, sx1 = 0, sy0 = 1, sy1 = 0;      // a culled row covers nothing
+    if (liverow) { sx0 = rmin.x >> ST_SHIFT; sx1 = (rmax.x - 1) >> ST_SHIFT; sy0 = rmin.y >> ST_SHIFT; sy1 = (rmax.y - 1) >> ST_SHIFT; }
+    const uint32_t rectpack = (uint32_t)rmin.x | ((uint32_t)rmin.y << 8) | ((uint32_t)rmax.x << 16) | ((uint32_t)rmax.y << 24);
+    __syncthreads();
+    if (timed) tq[2] = clock64();
+    // exclusive scans over the super-tiles: list starts (entries) and first level-B blocks (segments of B_SEG entries)
+    for (int pass = 0; pass < 2; pass++) {
+        const int sI = threadIdx.x;
+        const uint32_t n = sI < S ? tot[sI] : 0u;
+        const uint32_t mine = pass == 0 ? n : (n + B_SEG - 1) / B_SEG;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = __shfl_up(inc, o); if (lane >= o) inc += nb; }
+        if (lane == 63) scn[wv] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t run = 0; for (int q = 0; q < 16; q++) { const uint32_t v = scn[q]; scn[q] = run; run += v; } scn[16] = run; }
+        __syncthreads();
+        const uint32_t excl = scn[wv] + inc - mine, total_all = scn[16];
+        __syncthreads();
+        if (pass == 0) {
+            if (sI < S) { cur[sI] += excl; if (blockIdx.x == 0) b.rangesA[sI] = excl; }
+            if (threadIdx.x == 0 && blockIdx.x == 0) b.rangesA[S] = total_all;
+        } else if (blockIdx.x == 0) {
+            if (sI < S) b.segstart[sI] = excl;
+            if (threadIdx.x == 0) b.segstart[S] = total_all;
+        }
+    }
+    if (timed) tq[3] = clock64();
+    // pass 1: the wave's entries per super-tile.  Super-tiles in blocks of 64: a row's covered ones as a 64-bit mask, the 64 masks
+    // transposed across the wave -- lane t then holds the rows that cover super-tile 64 j + t, in row order
+    uint32_t *mycnt = wcnt + wv * S;
+    const int nblk64 = (S + 63) >> 6;
+    auto row_mask = [&](int j) {
+        unsigned long long mk = 0ull;
+        for (int y = sy0; y <= sy1; y++)
+            for (int x = sx0; x <= sx1; x++) {
+                const int st = y * b.sgx + x - 64 * j;
+                if (st >= 0 && st < 64) mk |= 1ull << st;
+            }
+        return mk;
+    };
+    for (int j = 0; j < nblk64; j++) {
+        const unsigned long long col = wave_transpose64(row_mask(j), lane);
+        if (64 * j + lane < S) mycnt[64 * j + lane] = (uint32_t)__popcll(col);
+    }
+    __syncthreads();
+    for (int st = threadIdx.x; st < S; st += 1024) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const uint32_t v = wcnt[w * S + st]; wcnt[w * S + st] = run; run += v; }
+    }
+    __syncthreads();
+    if (timed) tq[4] = clock64();
+    // pass 2: lane t walks the rows of its super-tile in order and writes their entries one after the other
+    for (int j = 0; j < nblk64; j++) {
+        unsigned long long col = wave_transpose64(row_mask(j), lane);
+        const int st = min(64 * j + lane, S - 1);
+        uint32_t pos = cur[st] + mycnt[st];
+        while (__ballot(col != 0ull)) {
+            const bool have = col != 0ull;
+            const int r = have ? __builtin_ctzll(col) : 0;
+            col &= col - 1ull;
+            const uint32_t ri = (uint32_t)__shfl((int)idx, r), rr = (uint32_t)__shfl((int)rectpack, r);
+            if (have) { b.la_idx[pos] = ri; b.la_rect[pos] = rr; pos++; }
+        }
+    }
+    if (timed) {
+        tq[5] = clock64();
+        for (int q = 0; q < 5; q++) timing[q] = tq[q + 1] - tq[q];
+    }
+}
+
+// the (super-tile, segment) of level-B block blk: the last super-tile whose first block is <= blk; false past the last block
+__device__ __forceinline__ bool bin2_segment(const Bin2 &b, int blk, int &s, uint32_t &e0, uint32_t &e1)
+{
+    if ((uint32_t)blk >= b.segstart[b.S]) return false;
+    int lo = 0, hi = b.S - 1;
+    while (lo < hi) {   // largest s with segstart[s] <= blk (super-tiles without entries share their successor's start: skipped)
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.segstart[mid] <= (uint32_t)blk) lo = mid; else hi = mid - 1;
+    }
+    s = lo;
+    const uint32_t seg = (uint32_t)blk - b.segstart[s];
+    e0 = b.rangesA[s] + seg * B_SEG;
+    e1 = min(e0 + (uint32_t)B_SEG, b.rangesA[s + 1]);
+    return true;
+}
+
+// tiles of the rect inside the super-tile at tile origin (ox, oy): bit 8 y + x
+__device__ __forceinline__ unsigned long long bin2_mask(uint32_t rect, int ox, int oy)
+{
+    const int x0 = (int)(rect & 255u) - ox, y0 = (int)((rect >> 8) & 255u) - oy;
+    const int x1 = (int)((rect >> 16) & 255u) - ox, y1 = (int)(rect >> 24) - oy;
+    const int lx0 = max(x0, 0), lx1 = min(x1, 8), ly0 = max(y0, 0), ly1 = min(y1, 8);
+    if (lx0 >= lx1 || ly0 >= ly1) return 0ull;
+    const unsigned long long xm = (unsigned long long)(((1u << lx1) - 1u) & ~((1u << lx0) - 1u));
+    const unsigned long long rows = (ly1 == 8 ? ~0ull : ((1ull << (8 * ly1)) - 1ull)) & ~((1ull << (8 * ly0)) - 1ull);
+    return (xm * 0x0101010101010101ull) & rows;
+}
+
+constexpr int B_CH = B_SEG / 256;   // chunks of 256 entries per segment; a wave owns 64 entries of each
+
+// Level B, counts: blocks walk the segments blk, blk + gridDim.x, ..  Per wave chunk the 64 masks are transposed: lane t then
+// holds which of the 64 entries cover tile t, and its popcount is the tile's count -- no loop over tiles.
+__global__ void __launch_bounds__(256) bin2_countB_kernel(int gx, int gy, Bin2 b)
+{
+    __shared__ uint32_t wsum[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t nseg = b.segstart[b.S];
+    for (uint32_t blk = blockIdx.x; blk < nseg; blk += gridDim.x) {
+        int s;
+        uint32_t e0, e1;
+        bin2_segment(b, (int)blk, s, e0, e1);
+        const int ox = (s % b.sgx) << ST_SHIFT, oy = (s / b.sgx) << ST_SHIFT;
+        uint32_t acc = 0;   // lane t: entries of this wave's chunks that cover tile t
+#pragma unroll
+        for (int c = 0; c < B_CH; c++) {
+            const uint32_t e = e0 + c * 256 + threadIdx.x;
+            const unsigned long long m = e < e1 ? bin2_mask(b.la_rect[e], ox, oy) : 0ull;
+            acc += (uint32_t)__popcll(wave_transpose64(m, lane));
+        }
+        wsum[wv][lane] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int t = threadIdx.x;
+            const uint32_t tot = wsum[0][t] + wsum[1][t] + wsum[2][t] + wsum[3][t];
+            b.cntB[(size_t)blk * 64 + t] = tot;
+            const int tx = ox + (t & 7), ty = oy + (t >> 3);
+            if (tot && tx < gx && ty < gy) atomicAdd(&b.total[ty * gx + tx], tot);
+        }
+        __syncthreads();
+    }
+}
+
+// Level B, writes.  Counts per wave chunk as above; positions: the tile's start (ranges) + the super-tile's earlier segments +
+// the segment's earlier wave chunks; then, tile by tile, ballot(entry covers it) ranks the wave's entries: one run of
+// consecutive addresses per wave chunk and tile.
+__global__ void __launch_bounds__(256) bin2_writeB_kernel(int gx, int gy, const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list,
+                                                          Bin2 b, unsigned long long *__restrict__ timing)
+{
+    __shared__ uint32_t wcnt[4 * B_CH][64];   // per (chunk, wave) and tile: count, then the position of its first entry
+    const bool timed = timing != nullptr && blockIdx.x == 100 && threadIdx.x == 0;   // diagnostic (ED3DGS_BIN_TIMING)
+    unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t nseg = b.segstart[b.S];
+    for (uint32_t blk = blockIdx.x; blk < nseg; blk += gridDim.x) {
+        if (timed) tq[0] = clock64();
+        int s;
+        uint32_t e0, e1;
+        bin2_segment(b, (int)blk, s, e0, e1);
+        const int ox = (s % b.sgx) << ST_SHIFT, oy = (s / b.sgx) << ST_SHIFT;
+        unsigned long long m[B_CH];
+        uint32_t id[B_CH];
+#pragma unroll
+        for (int c = 0; c < B_CH; c++) {
+            const uint32_t e = e0 + c * 256 + threadIdx.x;
+            const bool in = e < e1;
+            const uint32_t ee = in ? e : e0;
+            id[c] = b.la_idx[ee];
+            m[c] = in ? bin2_mask(b.la_rect[ee], ox, oy) : 0ull;
+        }
+        if (timed) tq[1] = clock64();
+#pragma unroll
+        for (int c = 0; c < B_CH; c++) wcnt[c * 4 + wv][lane] = (uint32_t)__popcll(wave_transpose64(m[c], lane));
+        __syncthreads();
+        if (timed) tq[2] = clock64();
+        if (threadIdx.x < 64) {
+            const int t = threadIdx.x;
+            const int tx = ox + (t & 7), ty = oy + (t >> 3);
+            uint32_t run = (tx < gx && ty < gy) ? ranges[ty * gx + tx].x : 0u;
+            uint32_t q = b.segstart[s];   // the super-tile's earlier segments (eight loads in flight: a crowded super-tile has hundreds)
+            for (; q + 8 <= blk; q += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = b.cntB[(size_t)(q + k) * 64 + t];
+#pragma unroll
+                for (int k = 0; k < 8; k++) run += v[k];
+            }
+            for (; q < blk; q++) run += b.cntB[(size_t)q * 64 + t];
+#pragma unroll
+            for (int k = 0; k < 4 * B_CH; k++) { const uint32_t v = wcnt[k][t]; wcnt[k][t] = run; run += v; }
+        }
+        __syncthreads();
+        if (timed) tq[3] = clock64();
+#pragma unroll
+        for (int c = 0; c < B_CH; c++) {
+            const uint32_t mlo = (uint32_t)m[c], mhi = (uint32_t)(m[c] >> 32);   // 32-bit tests: a 64-bit shift per tile is quarter rate
+            const int first = (int)wcnt[c * 4 + wv][lane];   // lane t: where this wave chunk's first entry of tile t goes
+#pragma unroll 4
+            for (int t = 0; t < 32; t++) {
+                const uint32_t bitm = 1u << t;
+                const bool b0 = (mlo & bitm) != 0u, b1 = (mhi & bitm) != 0u;
+                const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane(first, t), p1 = (uint32_t)__builtin_amdgcn_readlane(first, t + 32);
+                if (b0) point_list[p0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0u))] = id[c];
+                if (b1) point_list[p1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal1, 0u))] = id[c];
+            }
+        }
+        __syncthreads();
+        if (timed) { tq[4] = clock64(); for (int q = 0; q < 4; q++) timing[8 + q] = tq[q + 1] - tq[q]; }
+    }
+}
+
 // K5: CR/rasterizer_impl.cu:151-173
 __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint32_t *__restrict__ tile_keys,
                                                                    uint32_t *__restrict__ ranges)
@@ -654,16 +973,60 @@ void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ran
     hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, ranges);
 }
 
-size_t bin_transpose_bytes(int P, int T)   // the C matrix + the tile totals, or 0 when the tile counters do not fit in LDS
+static bool bin_two_level(int gx, int gy)
 {
+    const int sgx = (gx + 7) >> 3, sgy = (gy + 7) >> 3;
+    return gx < 256 && gy < 256 && sgx * sgy <= 1024 && !getenv("ED3DGS_BIN_ONE_LEVEL");
+}
+
+size_t bin_transpose_bytes(int P, int W, int H, int R)   // scratch behind the binning state, or 0 when the tile counters do not fit in LDS
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
     if ((size_t)T * sizeof(uint32_t) > 48 * 1024 || P <= 0) return 0;
+    if (bin_two_level(gx, gy)) {
+        const size_t S = (size_t)((gx + 7) >> 3) * ((gy + 7) >> 3), BA = ((size_t)P + A_ROWS - 1) / A_ROWS;
+        const size_t maxseg = (size_t)(R > 0 ? R : 0) / B_SEG + S + 1;
+        return (BA * S + 2 * (S + 1) + maxseg * 64 + (size_t)T) * sizeof(uint32_t) + 1024;
+    }
     return ((size_t)((P + BIN_ROWS - 1) / BIN_ROWS) * T + (size_t)T) * sizeof(uint32_t) + 256;
 }
 
-void launch_bin_transpose(int P, int W, int H, const GeometryState &g, const int *radii, char *scratch, uint32_t *ranges,
-                          uint32_t *tile_order, uint32_t *tile_keys, uint32_t *point_list, hipStream_t s)
+void launch_bin_transpose(int P, int W, int H, int R, const GeometryState &g, const int *radii, char *scratch, uint32_t *ranges,
+                          uint32_t *tile_order, uint32_t *tile_keys, uint32_t *point_list, uint32_t *spare_a, uint32_t *spare_b,
+                          hipStream_t s)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy, B = (P + BIN_ROWS - 1) / BIN_ROWS;
+    if (bin_two_level(gx, gy)) {
+        Bin2 b;
+        b.sgx = (gx + 7) >> 3; b.sgy = (gy + 7) >> 3; b.S = b.sgx * b.sgy; b.BA = (P + A_ROWS - 1) / A_ROWS;
+        b.maxseg = (R > 0 ? R : 0) / B_SEG + b.S + 1;
+        uint32_t *p = reinterpret_cast<uint32_t *>(((uintptr_t)scratch + 127) & ~(uintptr_t)127);
+        b.CA = p; p += (size_t)b.BA * b.S;
+        b.rangesA = p; p += b.S + 1;
+        b.segstart = p; p += b.S + 1;
+        b.cntB = p; p += (size_t)b.maxseg * 64;
+        b.total = p;
+        b.la_idx = spare_a; b.la_rect = spare_b;   // the R-sized unsorted arrays of the radix path: free here, and R bounds the entries
+        hipLaunchKernelGGL(bin2_countA_kernel, dim3(b.BA), dim3(1024), (size_t)b.S * sizeof(uint32_t), s, P, T, g.rec, g.order, radii, gx, gy, b);
+        const size_t ldsA = ((size_t)18 * b.S + 32) * sizeof(uint32_t);
+        if (ldsA > 64 * 1024) (void)hipFuncSetAttribute((const void *)bin2_scatterA_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
+        static unsigned long long *t2buf = nullptr;
+        if (getenv("ED3DGS_BIN_TIMING") && !t2buf) (void)hipMalloc((void **)&t2buf, 16 * sizeof(unsigned long long));
+        unsigned long long *t2 = getenv("ED3DGS_BIN_TIMING") ? t2buf : nullptr;
+        hipLaunchKernelGGL(bin2_scatterA_kernel, dim3(b.BA), dim3(1024), ldsA, s, P, g.rec, g.order, radii, gx, gy, b, t2);
+        const int gridB = std::min(b.maxseg, 4096);   // blocks walk the segments (their number is known on the device only)
+        hipLaunchKernelGGL(bin2_countB_kernel, dim3(gridB), dim3(256), 0, s, gx, gy, b);
+        hipLaunchKernelGGL(bin_tiles_kernel, dim3(1), dim3(1024), 0, s, T, b.total, reinterpret_cast<uint2 *>(ranges), tile_order);
+        hipLaunchKernelGGL(bin2_writeB_kernel, dim3(gridB), dim3(256), 0, s, gx, gy, reinterpret_cast<const uint2 *>(ranges), point_list, b, t2);
+        if (t2) {   // diagnostic: cycles of one block's thread 0 per phase
+            unsigned long long t[16];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(t, t2, sizeof t, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[ed3dgs] bin2 scatterA cycles: column sums %llu row load %llu scans %llu count pass %llu write pass %llu | writeB: lookup + loads %llu counts %llu offsets %llu writes %llu\n",
+                    t[0], t[1], t[2], t[3], t[4], t[8], t[9], t[10], t[11]);
+        }
+        return;
+    }
     uint32_t *C = reinterpret_cast<uint32_t *>(((uintptr_t)scratch + 127) & ~(uintptr_t)127), *total = C + (size_t)B * T;
     const size_t lds = (size_t)T * sizeof(uint32_t);
     hipLaunchKernelGGL(bin_count_kernel, dim3(B), dim3(256), lds, s, P, T, g.rec, g.order, radii, gx, gy, C);
