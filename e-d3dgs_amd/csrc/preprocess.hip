@@ -418,10 +418,11 @@ __global__ void __launch_bounds__(1024) bin_tiles_kernel(int T, const uint32_t *
             if (t0 + q < T) {
                 ranges[t0 + q] = n[q] ? make_uint2(run, run + n[q]) : make_uint2(0u, 0u);   // CR/rasterizer_impl.cu:388-395: untouched tiles stay (0, 0)
                 run += n[q];
-                atomicAdd(&hist[255 - min(255u, n[q] >> 3)], 1u);
+                if (order) atomicAdd(&hist[255 - min(255u, n[q] >> 3)], 1u);
             }
         }
     }
+    if (!order) return;   // ranges only (the two-level transpose orders the tiles inside its write launch)
     __syncthreads();
     if (tid < 64) {
         uint32_t v[4], s4 = 0;
@@ -804,13 +805,20 @@ __global__ void __launch_bounds__(256) bin2_countB_kernel(int gx, int gy, Bin2 b
     }
 }
 
+__device__ __forceinline__ void tile_order_body(int T, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order, uint32_t *hist,
+                                                uint32_t *cursor);
+
 // Level B, writes.  Counts per wave chunk as above; positions: the tile's start (ranges) + the super-tile's earlier segments +
 // the segment's earlier wave chunks; then, tile by tile, ballot(entry covers it) ranks the wave's entries: one run of
 // consecutive addresses per wave chunk and tile.
 __global__ void __launch_bounds__(256) bin2_writeB_kernel(int gx, int gy, const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list,
-                                                          Bin2 b, unsigned long long *__restrict__ timing)
+                                                          Bin2 b, unsigned long long *__restrict__ timing, int T, uint32_t *__restrict__ tile_order)
 {
     __shared__ uint32_t wcnt[4 * B_CH][64];   // per (chunk, wave) and tile: count, then the position of its first entry
+    // the last block (it has no segment of its own in any but the tiniest frames) orders the tiles for the tile kernels while the
+    // others write the lists: a launch of its own for that was 8 us of one block
+    __shared__ uint32_t ord_hist[256], ord_cursor[256];
+    if (blockIdx.x == gridDim.x - 1) tile_order_body(T, ranges, tile_order, ord_hist, ord_cursor);
     const bool timed = timing != nullptr && blockIdx.x == 100 && threadIdx.x == 0;   // diagnostic (ED3DGS_BIN_TIMING)
     unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -893,15 +901,20 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
 // of the C3 frame: makespan 897 vs 689 list entries per slot).  Blocks take tiles longest list first instead: a counting sort
 // of the tile ids by list length (buckets of 8 entries, descending), one block, LDS histogram.  Only the ORDER in which
 // tiles are processed changes; every tile's result is its own.
-__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order)
+__device__ __forceinline__ void tile_order_body(int T, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order, uint32_t *hist,
+                                                uint32_t *cursor)
 {
-    __shared__ uint32_t hist[256], cursor[256];
-    const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int q = tid; q < 256; q += nt) hist[q] = 0;
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint2 r = ranges[t];
-        atomicAdd(&hist[255 - min(255u, (r.y - r.x) >> 3)], 1u);
+    // eight list lengths per thread in flight: with a load -> LDS atomic chain per tile the loop is one memory latency per tile
+    for (int t0 = tid; t0 < T; t0 += 8 * nt) {
+        uint32_t n[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint2 r = ranges[min(t0 + q * nt, T - 1)]; n[q] = r.y - r.x; }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (t0 + q * nt < T) atomicAdd(&hist[255 - min(255u, n[q] >> 3)], 1u);
     }
     __syncthreads();
     if (tid < 64) {   // exclusive scan of the 256 buckets by one wave: 4 per lane + a wave scan
@@ -916,10 +929,23 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2 *__
         for (int i = 0; i < 4; i++) { cursor[4 * tid + i] = base; base += v[i]; }
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint2 r = ranges[t];
-        order[atomicAdd(&cursor[255 - min(255u, (r.y - r.x) >> 3)], 1u)] = (uint32_t)t;
+    for (int t0 = tid; t0 < T; t0 += 8 * nt) {
+        uint32_t n[8], pos[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint2 r = ranges[min(t0 + q * nt, T - 1)]; n[q] = r.y - r.x; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) pos[q] = (t0 + q * nt < T) ? atomicAdd(&cursor[255 - min(255u, n[q] >> 3)], 1u) : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (t0 + q * nt < T) order[pos[q]] = (uint32_t)(t0 + q * nt);
     }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t hist[256], cursor[256];
+    tile_order_body(T, ranges, order, hist, cursor);
 }
 
 // the reference's 64-bit sort keys, for the parity tests' state view only
@@ -1016,8 +1042,9 @@ void launch_bin_transpose(int P, int W, int H, int R, const GeometryState &g, co
         hipLaunchKernelGGL(bin2_scatterA_kernel, dim3(b.BA), dim3(1024), ldsA, s, P, g.rec, g.order, radii, gx, gy, b, t2);
         const int gridB = std::min(b.maxseg, 4096);   // blocks walk the segments (their number is known on the device only)
         hipLaunchKernelGGL(bin2_countB_kernel, dim3(gridB), dim3(256), 0, s, gx, gy, b);
-        hipLaunchKernelGGL(bin_tiles_kernel, dim3(1), dim3(1024), 0, s, T, b.total, reinterpret_cast<uint2 *>(ranges), tile_order);
-        hipLaunchKernelGGL(bin2_writeB_kernel, dim3(gridB), dim3(256), 0, s, gx, gy, reinterpret_cast<const uint2 *>(ranges), point_list, b, t2);
+        hipLaunchKernelGGL(bin_tiles_kernel, dim3(1), dim3(1024), 0, s, T, b.total, reinterpret_cast<uint2 *>(ranges), (uint32_t *)nullptr);
+        hipLaunchKernelGGL(bin2_writeB_kernel, dim3(gridB), dim3(256), 0, s, gx, gy, reinterpret_cast<const uint2 *>(ranges), point_list, b, t2, T,
+                           tile_order);
         if (t2) {   // diagnostic: cycles of one block's thread 0 per phase
             unsigned long long t[16];
             (void)hipStreamSynchronize(s);
