@@ -31,7 +31,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-operand MFMA peak (MI355X_MICROARCH.md, matrix-core table)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
-MODE_VARS = ("ED3DGS_DEFORM_FP32_MFMA", "ED3DGS_DEFORM_BF16X3", "ED3DGS_DEFORM_BF16X6", "ED3DGS_DEFORM_NO_PIPE")
+MODE_OPTS = ("DEFORM_FP32_MFMA", "DEFORM_BF16X3", "DEFORM_NO_PIPE")   # library switches (ed3dgs_set_option) that select another MLP multiply mode
 WORKLOADS = {
     "C3": dict(P=200_000, W=1920, H=1080, cams=8, frames=50, deform=True,
                name="C3: 200k Gaussians, 8 cams x 50 timesteps, 1080p, deform MLP W=128 D=1, depth+normal (FTT)"),
@@ -75,6 +75,8 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     L = _lib.lib()
     stats_acc = torch.zeros(4, device=device)
     stats_out = [torch.zeros(3, device=device), torch.zeros(3, device=device)]
+    # opt-in: data-parallel training -- buckets all-reduced from autograd hooks as their gradients land
+    reducer = D.BucketedGradReducer(params) if dp_grads else None
 
     def step(item, backward=True, coord=False):
         ci, fi = D.item_of(item, wl["cams"], F)
@@ -103,8 +105,8 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
         if inflight:
             inflight.pop().wait()
         inflight.append(D.allreduce_sum_async(stats))
-        if dp_grads:             # opt-in: data-parallel training, mean of the ranks' gradients
-            D.allreduce_gradients_(params)
+        if reducer is not None:  # mean of the ranks' gradients (the collectives were issued during the backward)
+            reducer.finish()
         if step.probe is not None:   # untimed passes only: look at the gradients before they are dropped
             step.probe(model)
         for p in params:
@@ -283,25 +285,34 @@ def rehearse(a, D):
     inflight = []
     D.barrier()
     t0 = time.perf_counter()
+    items = [D.strided_item(mine, k) % n_items for k in range(a.steps)]   # the item schedule of the real path
+    t_step = []
     for k in range(a.steps):
-        stats = torch.tensor([float(mine[k % len(mine)] % n_items), 0.0, 1.0])
+        t1 = time.perf_counter()
+        stats = torch.tensor([float(items[k]), 0.0, 1.0])
         if inflight:
             inflight.pop().wait()
         inflight.append(D.allreduce_sum_async(stats))
+        t_step.append((time.perf_counter() - t1) * 1e3)
     while inflight:
         last = inflight.pop().wait()
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, "cpu")
     counts = torch.zeros(world); counts[rank] = a.steps
     D.allreduce_sum_(counts)
+    rank_step_ms = D.gather_per_rank(percentiles(t_step)["median"], "cpu")     # the per-rank fields of the real line
+    rank_num_rendered = D.gather_per_rank(float(sum(items)) / max(len(items), 1), "cpu")
+    cams = sorted({D.item_of(i, wl["cams"], wl["frames"])[0] for i in items})
+    ncams = D.gather_per_rank(len(cams), "cpu")
     if rank == 0:
         print(json.dumps({"metric": "REHEARSAL of the launcher (stub step, no GPU work) -- not a measurement", "value": None,
                           "rehearsal": True, "n_gpus": world, "gpus_arg": a.gpus, "steps": a.steps, "warmup": a.warmup,
                           "backend": dist.get_backend() if dist.is_initialized() else None, "items_per_rank": counts.tolist(),
                           "last_step_ranks_counted": float(last[2]), "seconds": dt,
+                          "step_ms_median_per_rank": rank_step_ms, "mean_num_rendered_per_rank": rank_num_rendered,
+                          "rank0_items_timed": items, "rank0_cameras_timed": cams, "cameras_timed_per_rank": ncams,
                           "launched_by_bench": bool(os.environ.get("ED3DGS_BENCH_LAUNCHED"))}))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    D.destroy()
 
 
 def main():
@@ -320,6 +331,7 @@ def main():
     if torch.cuda.is_available() and torch.cuda.device_count() > 0:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     rank, world, local = D.init()
+    backend_name = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
     if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the torchrun environment has WORLD_SIZE=%d -- refusing to report a line "
                          "whose n_gpus is not what was asked for" % (a.gpus, world))
@@ -337,7 +349,7 @@ def main():
     step = make_step(model, cams, grads, wl, device, dp_grads=a.dp_grads)
     n_items = wl["cams"] * wl["frames"]
     my_items = D.shard_items(max(n_items, world), rank, world)
-    item_at = lambda k: my_items[k % len(my_items)] % n_items
+    item_at = lambda k: D.strided_item(my_items, k) % n_items   # coprime stride: a 20-step run visits every camera
     ceiling = hbm_ceiling(device) if rank == 0 else None
 
     # ---- untimed: warm-up + algorithmic-byte bookkeeping of the items the timed region will visit ----
@@ -368,7 +380,7 @@ def main():
     tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(NS)]
     # K7's work counts (visited iterations, blended pairs, ...): a short pass of its own -- counting slows the kernel down
     n_count = min(4, a.steps)
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(n_count + 2), ctypes.c_uint(2 | (1 << 30)))
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(n_count + 2), ctypes.c_uint(3 | (1 << 30)))
     # ... and the rows the deformation backward walks: Gaussians with a non-zero upstream gradient = non-zero dL/d embedding rows
     active_rows = []
     if wl.get("deform", True):
@@ -380,10 +392,13 @@ def main():
     torch.cuda.synchronize()
     cnt_ms, cnt_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(cnt_ms, cnt_n)
-    k7_counts = (ctypes.c_ulonglong * 4)()
-    L.ed3dgs_profile_tile_backward_counts(k7_counts)
-    k7_work = [k7_counts[i] / max(cnt_n[1], 1) for i in range(4)]   # per launch: iterations, pairs, staged, kept
+    NCNT = 16  # ED3DGS_PROF_COUNTERS
+    tile_counts = (ctypes.c_ulonglong * NCNT)()
+    L.ed3dgs_profile_tile_counts(tile_counts, ctypes.c_int(NCNT))
+    k7_work = [tile_counts[i] / max(cnt_n[1], 1) for i in range(12)]   # per launch: iterations, pairs, staged, kept, quadrant histogram, halves
+    k6_work = [tile_counts[12 + i] / max(cnt_n[0], 1) for i in range(4)]  # per launch: iterations, pairs, staged, kept
     k7_count_ms = cnt_ms[1] / max(cnt_n[1], 1)
+    k6_count_ms = cnt_ms[0] / max(cnt_n[0], 1)
     dom = max([i for i in range(NS) if i != 4], key=lambda i: tab_avg[i])   # the dominant single KERNEL
 
     # ---- timed: exactly K steps; events only around the dominant kernel and K7 ----
@@ -405,6 +420,7 @@ def main():
     # K6, K7, deform fwd, deform dgrad, deform wgrad (+ its three launches): timed-region events where taken, else the
     # instrumented pass
     avg_ms = [slot_ms[i] / slot_n[i] if slot_n[i] else tab_avg[i] for i in range(NS)]
+    dt_local = dt
     dt = D.max_over_ranks(dt, device)
 
     log("timed region done: %.3f ms/step" % (dt / a.steps * 1e3))
@@ -420,9 +436,10 @@ def main():
 
     # ---- extras, not the headline: the same K steps / K renders with the deformation MLP in its other two modes ----
     def other_mode(var, note):
-        if a.no_other_modes or not wl["deform"] or any(os.environ.get(v) for v in MODE_VARS):
+        # not on a multi-rank run (the extra passes carry barriers of their own and are not part of the scaling measurement)
+        if a.no_other_modes or world > 1 or not wl["deform"] or any(_lib.get_option(v) for v in MODE_OPTS):
             return None
-        os.environ[var] = "1"      # read by the library at every call
+        _lib.set_option(var, 1)
         try:
             for k in range(3):
                 step(item_at(k))
@@ -443,22 +460,30 @@ def main():
             return {"ms_per_step": dt_b / a.steps * 1e3, "value": world * a.steps / dt_b,
                     "render_fps": world * a.steps / dt_br, "note": note}
         finally:
-            del os.environ[var]
+            _lib.set_option(var, 0)
 
-    mode = "fp32_mfma" if os.environ.get("ED3DGS_DEFORM_FP32_MFMA") or os.environ.get("ED3DGS_DEFORM_NO_PIPE") else \
-           "bf16x3" if os.environ.get("ED3DGS_DEFORM_BF16X3") and not os.environ.get("ED3DGS_DEFORM_BF16X6") else "exact_split"
-    f32m = other_mode("ED3DGS_DEFORM_FP32_MFMA",
+    mode = "fp32_mfma" if _lib.get_option("DEFORM_FP32_MFMA") or _lib.get_option("DEFORM_NO_PIPE") else \
+           "bf16x3" if _lib.get_option("DEFORM_BF16X3") else "exact_split"
+    f32m = other_mode("DEFORM_FP32_MFMA",
                       "ED3DGS_DEFORM_FP32_MFMA=1: every MLP contraction on v_mfma_f32_32x32x2_f32 (the round's first kernels; "
                       "same results as the headline mode to fp32 rounding, DESIGN.md section 2)")
-    b3 = other_mode("ED3DGS_DEFORM_BF16X3",
+    b3 = other_mode("DEFORM_BF16X3",
                     "opt-in ED3DGS_DEFORM_BF16X3=1: two bf16 pieces per operand, three products, fp32 accumulation "
                     "(deformation outputs / gradients within 1e-6 / 2e-5 of the fp32 values, tolerance 1e-4; REDUCED "
                     "precision, never the headline)")
 
+    # per-rank figures (load imbalance must be visible in the one line rank 0 prints): median step, mean instance count
+    mean = lambda v: sum(v) / max(len(v), 1)
+    rank_step_ms = D.gather_per_rank(percentiles(step_ms)["median"], device)
+    rank_num_rendered = D.gather_per_rank(mean(rsum), device)
+    rank_wall_ms = D.gather_per_rank(dt_local / a.steps * 1e3, device)
+    items_timed = [item_at(k) for k in range(a.steps)]
+    cams_timed = sorted({D.item_of(i, wl["cams"], wl["frames"])[0] for i in items_timed})
+    D.barrier()
+    D.destroy()
     if rank != 0:
         return
     HW, T = wl["H"] * wl["W"], ((wl["W"] + 15) // 16) * ((wl["H"] + 15) // 16)
-    mean = lambda v: sum(v) / max(len(v), 1)
     bytes_k7 = 128.0 * mean(reff) + 68.0 * HW + 8.0 * T   # FTT: (g_b + 4a) R_eff + r HW + 8T  
     bytes_k6 = 68.0 * mean(reff) + 56.0 * HW + 8.0 * T
     k6_ms, k7_ms = avg_ms[0], avg_ms[1]
@@ -466,7 +491,7 @@ def main():
     # HBM traffic per launch: NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes); read from the
     # newest committed summary of such passes over this same command, and labelled as such (`traffic_source`)
     pmc, traffic_source = {}, None
-    for prof_name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for prof_name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         prof = os.path.join(ROOT, "profiles", prof_name)
         if not os.path.exists(prof):
             continue
@@ -503,7 +528,7 @@ def main():
     tfl = lambda mac, ms, rows=None: 2.0 * mac * (wl["P"] if rows is None else rows) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # the backward kernels walk only the rows with a non-zero upstream gradient (csrc/deform.hip, deform_active_rows_body):
     # their rates are priced on the rows they process, not on P
-    dense_bwd = bool(os.environ.get("ED3DGS_DEFORM_DENSE_BWD")) or mode != "exact_split"
+    dense_bwd = bool(_lib.get_option("DEFORM_DENSE_BWD")) or mode != "exact_split"
     rows_bwd = wl["P"] if (dense_bwd or not active_rows) else mean(active_rows)
     kernels = {
         "_source": "separate instrumented pass of the same %d steps (event pairs around every kernel), not the timed region" % a.steps,
@@ -532,6 +557,27 @@ def main():
                  "frac": it_per_s * K7_ISSUE_CYCLES_PER_ITER / (1024 * 2.4e9), "pairs_per_s": k7_work[1] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                  "note": "vector-instruction issue cycles the visited iterations need / cycles the 1024 SIMDs offer in the launch; the "
                          "counts from a separate pass over the first %d items (counting slows K7 to %.3f ms per launch; that is not the time used)" % (n_count, k7_count_ms)}
+    valu_roof["quadrants_with_a_blended_pixel_hist_1_2_3_4"] = k7_work[4:8]
+    valu_roof["mean_quadrants_per_iteration"] = (sum((i + 1) * k7_work[4 + i] for i in range(4)) / k7_work[0]) if k7_work[0] else 0.0
+    valu_roof["mean_top_bottom_halves_per_iteration"] = k7_work[8] / k7_work[0] if k7_work[0] else 0.0
+    valu_roof["mean_left_right_halves_per_iteration"] = k7_work[9] / k7_work[0] if k7_work[0] else 0.0
+    # K6 against the same roof (ISA of render_forward_kernel<false,true>, tools/isa.sh: a list entry kept by the tile-level reject
+    # costs 44 four-cycle vector instructions + 4 v_exp_f32 for the per-pixel tests; one that blends anything, 86 more)
+    K6_TEST_CYCLES, K6_BLEND_CYCLES = 44 * 4 + 4 * 8, 86 * 4
+    k6_cycles = k6_work[3] * K6_TEST_CYCLES + k6_work[0] * K6_BLEND_CYCLES
+    valu_roof_k6 = {"visited_iterations_per_launch": k6_work[0], "blended_pairs_per_launch": k6_work[1],
+                    "list_entries_staged_per_launch": k6_work[2], "entries_kept_by_tile_reject_per_launch": k6_work[3],
+                    "pairs_per_iteration": k6_work[1] / k6_work[0] if k6_work[0] else 0.0,
+                    "issue_cycles_per_kept_entry": K6_TEST_CYCLES, "extra_issue_cycles_per_visited_iteration": K6_BLEND_CYCLES,
+                    "issue_cycles_per_launch": k6_cycles,
+                    "frac": k6_cycles / (k6_ms * 1e-3 * 1024 * 2.4e9) if k6_ms > 0 else 0.0,
+                    "pairs_per_s": k6_work[1] / (k6_ms * 1e-3) if k6_ms > 0 else 0.0,
+                    "note": "vector-instruction issue cycles K6's kept entries and visited iterations need / cycles the 1024 SIMDs offer in "
+                            "the launch; counts from the same separate pass (counting slows K6 to %.3f ms per launch; not the time used)" % k6_count_ms}
+    roof_k6 = {"bound": "hbm", "kernel": "render_forward_kernel<false,true> (K6)", "achieved": bytes_k6 / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else 0.0,
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (bytes_k6 / (k6_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k6_ms > 0 else 0.0,
+               "traffic": pmc.get("render_forward_kernel<false,true>"), "traffic_source": traffic_source,
+               "algorithmic_bytes_per_launch": bytes_k6, "avg_launch_ms": k6_ms, "valu_roof": valu_roof_k6}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                "traffic": pmc.get("render_backward_kernel<false,true>"), "traffic_source": traffic_source,
@@ -563,10 +609,13 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "step_ms": dict(percentiles(step_ms), source="rank 0, hipEvent marks at the step boundaries of the timed region, on the launch stream"),
         "frames_per_s": world * a.steps / dt,
-        "ranks": {"world": world, "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-                  "rccl_ranks": world if (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
+        "ranks": {"world": world, "backend": backend_name,
+                  "rccl_ranks": world if backend_name == "nccl" else 0,
                   "items_per_rank": [a.steps] * world, "gpus_shared": bool(shared_gpu),
-                  "launched_by_bench": bool(os.environ.get("ED3DGS_BENCH_LAUNCHED"))},
+                  "launched_by_bench": bool(os.environ.get("ED3DGS_BENCH_LAUNCHED")),
+                  "step_ms_median_per_rank": rank_step_ms, "wall_ms_per_step_per_rank": rank_wall_ms,
+                  "mean_num_rendered_per_rank": rank_num_rendered,
+                  "rank0_items_timed": items_timed, "rank0_cameras_timed": cams_timed},
         "hbm_ceiling_measured_GBps": dict(ceiling, spec=HBM_PEAK_GBPS, note="1-GiB device-to-device copy and stream triad on this box, untimed section; `peak` in the rooflines stays the 8 TB/s spec"),
         "config": {"workload": wl["name"], "gaussians": wl["P"], "resolution": [wl["W"], wl["H"]],
                    "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step" + ("; + bucketed gradient all-reduce (--dp-grads)" if a.dp_grads else ""),
@@ -580,6 +629,7 @@ def main():
                                          "walks only these rows -- results identical to the dense walk (ED3DGS_DEFORM_DENSE_BWD=1)"},
         "roofline": roof,
         "roofline_tile_backward": roof_k7,
+        "roofline_tile_forward": roof_k6,
         "kernels": kernels,
     }
     res["deform_mode"] = {"mode": mode, "note": {

@@ -13,6 +13,32 @@
 
 namespace ed3 {
 
+// the switches of common.h: environment at load time, ed3dgs_set_option() afterwards
+int g_opt[OPT_COUNT];
+static const char *const g_opt_names[OPT_COUNT] = {
+#define X(n) #n,
+    ED3_OPTIONS(X)
+#undef X
+};
+static int opt_value_of(const char *v)
+{
+    if (!v || !*v) return 0;
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    return (end && end != v && !*end) ? (int)x : 1;   // "1", "0", "3"; anything else that is set counts as on
+}
+static const bool g_opt_loaded = [] {
+    for (int k = 0; k < OPT_COUNT; k++) g_opt[k] = opt_value_of(getenv((std::string("ED3DGS_") + g_opt_names[k]).c_str()));
+    return true;
+}();
+static int opt_index(const char *name)
+{
+    if (!name) return -1;
+    if (!strncmp(name, "ED3DGS_", 7)) name += 7;
+    for (int k = 0; k < OPT_COUNT; k++) if (!strcmp(name, g_opt_names[k])) return k;
+    return -1;
+}
+
 static thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
 bool check_hip(hipError_t e, const char *what)
@@ -86,8 +112,8 @@ struct Profiler {
     unsigned mask = 0;
     int n[ED3DGS_PROF_SLOTS] = {0};
     std::vector<hipEvent_t> e0[ED3DGS_PROF_SLOTS], e1[ED3DGS_PROF_SLOTS];
-    unsigned long long *counters = nullptr;   // device: K7's visited-iteration / pair / staged / kept counts while its slot is timed
-    unsigned long long counters_host[4] = {0, 0, 0, 0};
+    unsigned long long *counters = nullptr;   // device: the tile kernels' work counts (see render_backward.hip / render_forward.hip) while their slots are timed
+    unsigned long long counters_host[ED3DGS_PROF_COUNTERS] = {0};
 };
 static Profiler g_prof;
 bool prof_start(int slot, hipStream_t s)
@@ -163,7 +189,7 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5
-    const bool transpose = !getenv("ED3DGS_BIN_RADIX") && bin_transpose_bytes(P, width, height, 0) > 0;
+    const bool transpose = !opt(OPT_BIN_RADIX) && bin_transpose_bytes(P, width, height, 0) > 0;
     if (!transpose) {
         if (!run_scan_gather(geom.scan_space, geom.scan_size, geom.tiles_touched, geom.order, geom.offsets_sorted, P, s)) return ED3DGS_ERR_HIP;
         if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
@@ -205,7 +231,28 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
 extern "C" {
 
 const char *ed3dgs_last_error(void) { return g_error.c_str(); }
-int ed3dgs_abi_version(void) { return 3; }
+int ed3dgs_abi_version(void) { return 4; }
+
+int ed3dgs_set_option(const char *name, int value)
+{
+    const int k = opt_index(name);
+    if (k < 0) { set_error(std::string("ed3dgs_set_option: unknown option ") + (name ? name : "(null)")); return ED3DGS_ERR_INVALID; }
+    const int old = g_opt[k];
+    g_opt[k] = value;
+    return old;
+}
+int ed3dgs_get_option(const char *name)
+{
+    const int k = opt_index(name);
+    if (k < 0) { set_error(std::string("ed3dgs_get_option: unknown option ") + (name ? name : "(null)")); return ED3DGS_ERR_INVALID; }
+    return g_opt[k];
+}
+int ed3dgs_binning_path(int P, int width, int height)
+{
+    if (P <= 0 || width <= 0 || height <= 0) { set_error("ed3dgs_binning_path: bad sizes"); return ED3DGS_ERR_INVALID; }
+    if (opt(OPT_BIN_RADIX)) return 0;
+    return bin_transpose_level(P, width, height);
+}
 
 size_t ed3dgs_geometry_bytes(int P)
 {
@@ -274,7 +321,7 @@ int ed3dgs_rasterize_forward(
     const bool pf = prof_start(ED3DGS_PROF_TILE_FORWARD, s);
     launch_render_forward(width, height, img.ranges, bin.point_list, geom.rec, geom.rec_coord, focal_x, focal_y,
                           background, require_coord != 0, require_depth != 0, out_color, out_coord, out_mcoord,
-                          out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img, s);
+                          out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img, s, pf ? g_prof.counters : nullptr);
     if (pf) prof_stop(ED3DGS_PROF_TILE_FORWARD, s);
     if (!ok("render")) return ED3DGS_ERR_HIP;
     return R;
@@ -406,9 +453,9 @@ int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask)
             v->resize(max_samples);
             for (auto &e : *v) if (!check_hip(hipEventCreate(&e), "hipEventCreate")) return ED3DGS_ERR_HIP;
         }
-    if ((slot_mask >> ED3DGS_PROF_TILE_BACKWARD & 1u) && (slot_mask & ED3DGS_PROF_COUNT_WORK)) {   // counting costs K7 a few ballots per entry
-        if (!check_hip(hipMalloc((void **)&g_prof.counters, 4 * sizeof(unsigned long long)), "counter buffer") ||
-            !check_hip(hipMemset(g_prof.counters, 0, 4 * sizeof(unsigned long long)), "counter buffer")) return ED3DGS_ERR_HIP;
+    if ((slot_mask & (1u << ED3DGS_PROF_TILE_BACKWARD | 1u << ED3DGS_PROF_TILE_FORWARD)) && (slot_mask & ED3DGS_PROF_COUNT_WORK)) {   // counting costs the tile kernels a few ballots per entry
+        if (!check_hip(hipMalloc((void **)&g_prof.counters, ED3DGS_PROF_COUNTERS * sizeof(unsigned long long)), "counter buffer") ||
+            !check_hip(hipMemset(g_prof.counters, 0, ED3DGS_PROF_COUNTERS * sizeof(unsigned long long)), "counter buffer")) return ED3DGS_ERR_HIP;
     }
     g_prof.on = true;
     return 0;
@@ -418,7 +465,7 @@ int ed3dgs_profile_end_slots(double *ms_total, int *launches)
 {
     if (!g_prof.on) { set_error("ed3dgs_profile_end: not active"); return ED3DGS_ERR_INVALID; }
     g_prof.on = false;
-    static unsigned long long last_counters[4];
+    static unsigned long long last_counters[ED3DGS_PROF_COUNTERS];
     if (g_prof.counters) {
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(last_counters, g_prof.counters, sizeof last_counters, hipMemcpyDeviceToHost);
@@ -448,6 +495,12 @@ int ed3dgs_profile_tile_backward_counts(unsigned long long out4[4])
 {
     if (!out4) { set_error("ed3dgs_profile_tile_backward_counts: null pointer"); return ED3DGS_ERR_INVALID; }
     std::memcpy(out4, g_prof.counters_host, 4 * sizeof(unsigned long long));
+    return 0;
+}
+int ed3dgs_profile_tile_counts(unsigned long long *out, int n)
+{
+    if (!out || n < 0) { set_error("ed3dgs_profile_tile_counts: bad arguments"); return ED3DGS_ERR_INVALID; }
+    std::memcpy(out, g_prof.counters_host, (size_t)std::min(n, (int)ED3DGS_PROF_COUNTERS) * sizeof(unsigned long long));
     return 0;
 }
 

@@ -21,6 +21,23 @@ enum { R_X = 0, R_Y, R_CX, R_CY, R_CZ, R_W, R_R, R_G, R_B, R_TG, R_TS, R_RPX, R_
 enum { G_R = 0, G_G, G_B, G_TS, G_RPX, G_RPY, G_NX, G_NY, G_NZ, G_MX, G_MY, G_MZ, G_CX, G_CY, G_CW, G_OP };
 // coord gradient record: view_point[3], camera_plane[6], pad
 
+// ---- process-wide switches (A/B modes, diagnostics).  Read from the environment ONCE, when the library is loaded
+// (ED3DGS_<name>=<int>; any non-numeric non-empty value counts as 1), and changed afterwards only through
+// ed3dgs_set_option() -- no entry point reads the environment per call.
+#define ED3_OPTIONS(X) \
+    X(BIN_ONE_LEVEL) X(BIN_RADIX) X(BIN_TIMING) X(SORT_LIBRARY) \
+    X(DEFORM_BF16X3) X(DEFORM_DENSE_BWD) X(DEFORM_DW1_GENERIC) X(DEFORM_FP32_MFMA) X(DEFORM_FUSED_BWD) \
+    X(DEFORM_GENERIC_WGRAD) X(DEFORM_NO_PIPE) X(DEFORM_NO_TAIL) X(DEFORM_WGRAD_R1) X(FB_ABLATE) X(FWD_TIMING) \
+    X(PREP_SEQ) X(STATS_BLOCKS) X(WG_ABLATE) X(WG_TIMING)
+enum Opt {
+#define X(n) OPT_##n,
+    ED3_OPTIONS(X)
+#undef X
+    OPT_COUNT
+};
+extern int g_opt[OPT_COUNT];
+inline int opt(Opt o) { return g_opt[o]; }
+
 void set_error(const std::string &msg);
 bool check_hip(hipError_t e, const char *what);
 // bench.py's kernel timing (api.hip): true if a sample was opened on slot (then call prof_stop after the launches)
@@ -86,6 +103,7 @@ void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii,
                                 uint32_t *values, hipStream_t s);
 void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ranges, hipStream_t s);
 void launch_tile_order(int T, const uint32_t *ranges, uint32_t *tile_order, hipStream_t s);
+int bin_transpose_level(int P, int W, int H);   // 2: two-level transpose, 1: one-level, 0: neither fits (radix path)
 size_t bin_transpose_bytes(int P, int W, int H, int R);
 void launch_bin_transpose(int P, int W, int H, int R, const GeometryState &g, const int *radii, char *scratch, uint32_t *ranges,
                           uint32_t *tile_order, uint32_t *tile_keys, uint32_t *point_list, uint32_t *spare_a, uint32_t *spare_b,
@@ -106,7 +124,7 @@ void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t 
                            const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,
                            bool depth, float *out_color, float *out_coord, float *out_mcoord, float *out_depth,
                            float *out_mdepth, float *out_alpha, float *out_tongue, float *out_normal, ImageState img,
-                           hipStream_t s);
+                           hipStream_t s, unsigned long long *counters = nullptr);
 void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,
                             const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,
                             bool depth, const float *alphas, const float *normalmap, ImageState img,

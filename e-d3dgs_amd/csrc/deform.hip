@@ -24,37 +24,13 @@
 #include <vector>
 
 #include "common.h"
+#include "deform_common.h"
 
 namespace ed3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NHEAD = 5;
-constexpr int OTMAX = 2;   // output tiles of 32 per head (rgb: 48 -> 2)
-constexpr int FS_STRIDE = 1024;  // floats of frame state per stage (h, dh/dt need TD <= 448)
-
 __device__ __forceinline__ int fslot(int kk, int h) { return (kk & 3) + 8 * (kk >> 2) + 4 * h; }
-__host__ __device__ inline int head_nk(int k, int n_sh) { return k == 0 ? 3 : k == 1 ? 3 : k == 2 ? 4 : k == 3 ? 1 : 3 * n_sh; }
-
-struct ParamLayout {
-    size_t W1, b1, W2[NHEAD], b2[NHEAD], W3[NHEAD], b3[NHEAD], total;
-};
-__host__ __device__ inline ParamLayout param_layout(int W, int TD, int E, int n_sh)
-{
-    ParamLayout L;
-    size_t o = 0;
-    L.W1 = o; o += (size_t)W * (TD + E);
-    L.b1 = o; o += W;
-    for (int k = 0; k < NHEAD; k++) {
-        int nk = head_nk(k, n_sh);
-        L.W2[k] = o; o += (size_t)W * W;
-        L.b2[k] = o; o += W;
-        L.W3[k] = o; o += (size_t)nk * W;
-        L.b3[k] = o; o += nk;
-    }
-    L.total = o;
-    return L;
-}
 
 // fragment workspace of one stage (float offsets)
 struct FragLayout {
@@ -3977,7 +3953,7 @@ static bool validate(const ed3dgs_deform_cfg *c, const char *who)
     if (!c) { set_error(std::string(who) + ": null cfg"); return false; }
     if (c->P < 0) { set_error(std::string(who) + ": bad P"); return false; }
     if (!(c->W == 32 || c->W == 64 || c->W == 128 || c->W == 256)) { set_error(std::string(who) + ": net_width must be 32, 64, 128 or 256"); return false; }
-    if (c->D > 1) { set_error(std::string(who) + ": defor_depth > 1 is not supported by the fused MI355X path"); return false; }
+    if (c->D > MAX_EXTRA_TRUNK + 1) { set_error(std::string(who) + ": defor_depth must be <= 8"); return false; }
     if (c->E <= 0 || c->E % 32) { set_error(std::string(who) + ": gaussian_embedding_dim must be a multiple of 32"); return false; }
     if (c->TD <= 0 || c->TD > 448) { set_error(std::string(who) + ": temporal_embedding_dim must be in [1, 448]"); return false; }
     if (c->n_sh <= 0 || 3 * c->n_sh > 64 || (3 * c->n_sh) % 4) { set_error(std::string(who) + ": unsupported n_sh"); return false; }
@@ -4002,11 +3978,12 @@ static void fill_dev(const ed3dgs_deform_cfg *c, DeformDev &d, bool bwd)
 // the kept-activation backward exists for the LDS-pipelined, head-job configuration (width 128, embedding 32)
 static bool can_keep(const ed3dgs_deform_cfg *c)
 {
-    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48 && !getenv("ED3DGS_DEFORM_NO_PIPE") &&
-           !getenv("ED3DGS_DEFORM_GENERIC_WGRAD") && !getenv("ED3DGS_DEFORM_FUSED_BWD");
+    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48 && !opt(OPT_DEFORM_NO_PIPE) &&
+           !opt(OPT_DEFORM_GENERIC_WGRAD) && !opt(OPT_DEFORM_FUSED_BWD);
 }
 
 struct Workspace {
+    float *deep;   // defor_depth > 1: the layer-by-layer path's activations and gradients (deform_deep.hip)
     float *frag[2]; float *fs; float *A[2], *ZR[2], *GZ[2], *GHID[2];
     unsigned long long *MK[2];
     int *rows, *ctr;   // active rows of the backward and their counters (deform_active_rows_body)
@@ -4019,7 +3996,9 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
     for (int s = 0; s < 2; s++) obtain(p, w.frag[s], fl.total, 256);
     obtain(p, w.fs, 2 * FS_STRIDE, 256);
     w.rows = w.ctr = nullptr;
-    if (bwd) {
+    w.deep = nullptr;
+    if (c->D > 1) obtain(p, w.deep, deep_workspace_floats(c), 256);
+    if (bwd && c->D <= 1) {
         const size_t PW = (size_t)(c->P > 0 ? c->P : 0) * c->W;
         obtain(p, w.ctr, 64, 256);
         obtain(p, w.rows, (size_t)(c->P > 0 ? c->P : 0) + 64, 256);
@@ -4037,7 +4016,7 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
 
 static bool use_b3(const ed3dgs_deform_cfg *c)
 {
-    return getenv("ED3DGS_DEFORM_BF16X3") && !getenv("ED3DGS_DEFORM_FP32_MFMA") && c->E == 32 && c->W <= 128 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+    return opt(OPT_DEFORM_BF16X3) && !opt(OPT_DEFORM_FP32_MFMA) && c->E == 32 && c->W <= 128 && !opt(OPT_DEFORM_NO_PIPE);
 }
 // How the MLP multiplies.  3 (default): every fp32 operand is split EXACTLY into three bf16 pieces and the eight piece
 // products above 2^-32 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- each product more exact than one fp32
@@ -4046,8 +4025,8 @@ static bool use_b3(const ed3dgs_deform_cfg *c)
 // (ED3DGS_DEFORM_FP32_MFMA=1).  2: two pieces, three products, ~1e-5 (ED3DGS_DEFORM_BF16X3=1, opt-in fast mode).
 static int fwd_pieces(const ed3dgs_deform_cfg *c)
 {
-    if (c->E != 32 || c->W > 128 || getenv("ED3DGS_DEFORM_NO_PIPE") || getenv("ED3DGS_DEFORM_FP32_MFMA")) return 0;
-    if (getenv("ED3DGS_DEFORM_BF16X3") && !getenv("ED3DGS_DEFORM_BF16X6")) return 2;
+    if (c->E != 32 || c->W > 128 || opt(OPT_DEFORM_NO_PIPE) || opt(OPT_DEFORM_FP32_MFMA)) return 0;
+    if (opt(OPT_DEFORM_BF16X3)) return 2;
     return 3;
 }
 
@@ -4055,7 +4034,7 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
                      const Workspace &w, bool bwd, hipStream_t s, bool kept = false, const ZeroArgs *zero = nullptr,
                      const ActiveArgs *active = nullptr)
 {
-    ParamLayout pl = param_layout(c->W, c->TD, c->E, c->n_sh);
+    ParamLayout pl = param_layout(c->W, c->TD, c->E, c->n_sh, c->D);
     FragLayout fl = frag_layout(c->W, c->E, bwd);
     FragArgs fa;
     fa.W = c->W; fa.E = c->E; fa.TD = c->TD; fa.n_sh = c->n_sh; fa.NT = c->W / 32; fa.ET = c->E / 32; fa.bwd = bwd;
@@ -4100,7 +4079,7 @@ static bool run_prep(const ed3dgs_deform_cfg *c, const float *table, const float
     }
     if (active) { pa.aa = *active; pa.nb[6] = active->nblk; }
     const int nb_total = pa.nb[0] + pa.nb[1] + pa.nb[2] + pa.nb[3] + pa.nb[4] + pa.nb[5] + pa.nb[6];
-    if (getenv("ED3DGS_PREP_SEQ")) {   // diagnostic: the parts one launch at a time
+    if (opt(OPT_PREP_SEQ)) {   // diagnostic: the parts one launch at a time
         for (int q = 0; q < 7; q++) {
             if (!pa.nb[q]) continue;
             PrepArgs one = pa;
@@ -4137,7 +4116,7 @@ extern "C" {
 size_t ed3dgs_deform_param_count(const ed3dgs_deform_cfg *cfg)
 {
     if (!cfg) return 0;
-    return param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh).total;
+    return param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh, cfg->D).total;
 }
 
 size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backward)
@@ -4160,23 +4139,38 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && !params[s]) { set_error("ed3dgs_deform_forward: null params"); return ED3DGS_ERR_INVALID; }
     const bool have_sub = sub_xyz && sub_scales && sub_rot && sub_opacity && sub_sh;
     if (!have_sub && (sub_xyz || sub_scales || sub_rot || sub_opacity || sub_sh)) { set_error("ed3dgs_deform_forward: sub_* must be all set or all NULL"); return ED3DGS_ERR_INVALID; }
-    const bool keep = keep_activations && can_keep(cfg);
+    const bool deep = cfg->D > 1;   // deeper trunks: the layer-by-layer path (deform_deep.hip), which always keeps its pre-activations
+    const bool keep = keep_activations && (deep || can_keep(cfg));
+    if (deep && cfg->E != 32) { set_error("ed3dgs_deform_forward: gaussian_embedding_dim must be 32 for defor_depth > 1"); return ED3DGS_ERR_INVALID; }
     if (workspace_bytes < carve(cfg, keep, nullptr, nullptr)) { set_error("ed3dgs_deform_forward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     carve(cfg, keep, workspace, &w);   // keep: the backward's carve, so that A / ZR sit where the backward reads them
     ZeroArgs zf;
     std::memset(&zf, 0, sizeof zf);
-    if (keep) { zf.p[0] = reinterpret_cast<float *>(w.ctr); zf.n[0] = 4; }   // the backward's active-row counters start from zero
-    if (!run_prep(cfg, table, offsets, params, w, false, s, false, keep ? &zf : nullptr)) return ED3DGS_ERR_HIP;
+    if (keep && !deep) { zf.p[0] = reinterpret_cast<float *>(w.ctr); zf.n[0] = 4; }   // the backward's active-row counters start from zero
+    if (!run_prep(cfg, table, offsets, params, w, false, s, false, (keep && !deep) ? &zf : nullptr)) return ED3DGS_ERR_HIP;
+    if (deep) {
+        DeepIO io;
+        std::memset(&io, 0, sizeof io);
+        const FragLayout fld = frag_layout(cfg->W, cfg->E, false);
+        const float *bases[5] = {xyz, scales, rot, opacity, sh};
+        float *outs_[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
+        float *subs_[5] = {sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh};
+        io.emb = embedding; io.sh_rest = sh_rest;
+        for (int i = 0; i < 5; i++) { io.base[i] = bases[i]; io.out[i] = outs_[i]; io.sub[i] = have_sub ? subs_[i] : nullptr; }
+        for (int st = 0; st < 2; st++) { io.params[st] = params[st]; io.hb[st] = w.frag[st] + fld.HB; }
+        if (!deep_forward(cfg, io, w.deep, s)) return ED3DGS_ERR_HIP;
+        return keep ? 1 : 0;
+    }
     DeformDev d;
     std::memset(&d, 0, sizeof d);
     fill_dev(cfg, d, false);
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.keep = keep ? 1 : 0;
     static unsigned long long *fwd_timing = nullptr;
-    if (getenv("ED3DGS_FWD_TIMING") && !fwd_timing) (void)hipMalloc((void **)&fwd_timing, 32 * sizeof(unsigned long long));
-    d.timing = getenv("ED3DGS_FWD_TIMING") ? fwd_timing : nullptr;
+    if (opt(OPT_FWD_TIMING) && !fwd_timing) (void)hipMalloc((void **)&fwd_timing, 32 * sizeof(unsigned long long));
+    d.timing = opt(OPT_FWD_TIMING) ? fwd_timing : nullptr;
     if (keep) for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.MK[st] = w.MK[st]; }
     d.emb = embedding; d.xyz = xyz; d.scales = scales; d.rot = rot; d.opacity = opacity; d.sh = sh; d.sh_rest = sh_rest;
     float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
@@ -4184,7 +4178,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     for (int i = 0; i < 5; i++) { d.out[i] = outs[i]; d.sub[i] = have_sub ? subs[i] : nullptr; }
     const int nstrips = (cfg->P + 31) / 32;
     const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
-    const bool piped = d.NT <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+    const bool piped = d.NT <= 4 && cfg->E == 32 && !opt(OPT_DEFORM_NO_PIPE);
     const bool pf = prof_start(ED3DGS_PROF_DEFORM_FORWARD, s);
     dispatch_nt(d.NT, [&](auto nt) {
         constexpr int N = decltype(nt)::value;
@@ -4195,7 +4189,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
                 int n_en = 0;
                 for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k];
                 d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
-                d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G && !getenv("ED3DGS_DEFORM_NO_TAIL")) ? 1 : 0;
+                d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G && !opt(OPT_DEFORM_NO_TAIL)) ? 1 : 0;
                 const int np = fwd_pieces(cfg);
                 if (np == 3) {
                     const size_t lds3 = (size_t)2 * ((((size_t)N + OTMAX) * 1536 + 1023) & ~(size_t)1023) * sizeof(float);   // 1536-float tiles
@@ -4235,7 +4229,8 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            size_t workspace_bytes, int activations_kept, void *stream)
 {
     if (!validate(cfg, "ed3dgs_deform_backward")) return ED3DGS_ERR_INVALID;
-    if (activations_kept && !can_keep(cfg)) { set_error("ed3dgs_deform_backward: activations_kept set for a configuration that does not keep them"); return ED3DGS_ERR_INVALID; }
+    const bool deep = cfg->D > 1;
+    if (activations_kept && !deep && !can_keep(cfg)) { set_error("ed3dgs_deform_backward: activations_kept set for a configuration that does not keep them"); return ED3DGS_ERR_INVALID; }
     if (cfg->E != 32) { set_error("ed3dgs_deform_backward: gaussian_embedding_dim must be 32"); return ED3DGS_ERR_INVALID; }
     if (!table || !offsets || !g_table || !g_offsets || !workspace) { set_error("ed3dgs_deform_backward: null pointer"); return ED3DGS_ERR_INVALID; }
     if ((g_base_sh_dc == nullptr) != (g_base_sh_rest == nullptr)) { set_error("ed3dgs_deform_backward: g_base_sh_dc and g_base_sh_rest must both be set or both be NULL"); return ED3DGS_ERR_INVALID; }
@@ -4243,7 +4238,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && (!params[s] || !gparams[s])) { set_error("ed3dgs_deform_backward: null params"); return ED3DGS_ERR_INVALID; }
     if (workspace_bytes < carve(cfg, true, nullptr, nullptr)) { set_error("ed3dgs_deform_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    const ParamLayout pl = param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh);
+    const ParamLayout pl = param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh, cfg->D);
     ZeroArgs za;   // the accumulated outputs start from zero: part of the prepare launch (its own launch only when P == 0)
     za.p[0] = g_table; za.n[0] = (size_t)cfg->max_embeddings * cfg->TD;
     za.p[1] = g_offsets; za.n[1] = (size_t)cfg->num_offsets;
@@ -4251,20 +4246,20 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     za.p[4] = nullptr; za.n[4] = 0;
     bool tail_zeroed = false;
     // the default configuration (kept activations, exact three-piece kernels) walks the active rows only
-    const bool compact = activations_kept && cfg->P > 0 && cfg->P < (1 << 23) && g_embedding && fwd_pieces(cfg) == 3 && cfg->W == HJ_W && cfg->E == 32 &&
-                         3 * cfg->n_sh <= 48 && !getenv("ED3DGS_DEFORM_WGRAD_R1") && !getenv("ED3DGS_DEFORM_DW1_GENERIC") &&
-                         !getenv("ED3DGS_DEFORM_GENERIC_WGRAD") && !getenv("ED3DGS_DEFORM_FUSED_BWD") && !getenv("ED3DGS_DEFORM_DENSE_BWD");
+    const bool compact = !deep && activations_kept && cfg->P > 0 && cfg->P < (1 << 23) && g_embedding && fwd_pieces(cfg) == 3 && cfg->W == HJ_W && cfg->E == 32 &&
+                         3 * cfg->n_sh <= 48 && !opt(OPT_DEFORM_WGRAD_R1) && !opt(OPT_DEFORM_DW1_GENERIC) &&
+                         !opt(OPT_DEFORM_GENERIC_WGRAD) && !opt(OPT_DEFORM_FUSED_BWD) && !opt(OPT_DEFORM_DENSE_BWD);
     if (compact) {   // rows of skipped Gaussians (and the tail units' rows) of dL/d embedding start from zero
         za.p[4] = g_embedding; za.n[4] = (size_t)cfg->P * cfg->E;
         tail_zeroed = true;
     }
-    if (!compact) {   // the kept data gradient's tail units add into dL/d embedding rows that must start from zero (see below): zeroed here too
+    if (!compact && !deep) {   // the kept data gradient's tail units add into dL/d embedding rows that must start from zero (see below): zeroed here too
         const int NTc = cfg->W / 32;
-        const bool piped_c = NTc <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+        const bool piped_c = NTc <= 4 && cfg->E == 32 && !opt(OPT_DEFORM_NO_PIPE);
         if (piped_c && activations_kept && cfg->P > 0 && g_embedding) {
             const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
             const int full_rounds = n_bi / G, rem_units = n_bi % G;
-            if (rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && rem_units * 2 <= G && !getenv("ED3DGS_DEFORM_NO_TAIL")) {
+            if (rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && rem_units * 2 <= G && !opt(OPT_DEFORM_NO_TAIL)) {
                 const size_t r0 = (size_t)full_rounds * G * 128;
                 za.p[4] = g_embedding + r0 * cfg->E; za.n[4] = ((size_t)cfg->P - r0) * cfg->E;
                 tail_zeroed = true;
@@ -4304,7 +4299,18 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
             d.rows = w.rows; d.n_act = w.ctr + 2;
         }
     }
-    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0, &za, (compact || split_sh) ? &aa : nullptr)) return ED3DGS_ERR_HIP;
+    if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0 && !deep, &za, (compact || split_sh) ? &aa : nullptr)) return ED3DGS_ERR_HIP;
+    if (deep) {
+        DeepIO io;
+        std::memset(&io, 0, sizeof io);
+        const FragLayout fld = frag_layout(cfg->W, cfg->E, true);
+        const float *gg_[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
+        const float *gs_[5] = {gs_xyz, gs_scales, gs_rot, gs_opacity, gs_sh};
+        io.emb = embedding; io.g_emb = g_embedding;
+        for (int i = 0; i < 5; i++) { io.g[i] = gg_[i]; io.gs[i] = gs_[i]; }
+        for (int st = 0; st < 2; st++) { io.params[st] = params[st]; io.gparams[st] = gparams[st]; io.hb[st] = w.frag[st] + fld.HB; }
+        if (!deep_backward(cfg, io, w.deep, activations_kept != 0, s)) return ED3DGS_ERR_HIP;
+    }
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.emb = embedding;
     const float *gg[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
@@ -4312,13 +4318,15 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     for (int i = 0; i < 5; i++) { d.g[i] = gg[i]; d.gs[i] = gsub[i]; }
     for (int st = 0; st < 2; st++) { d.A[st] = w.A[st]; d.ZR[st] = w.ZR[st]; d.GZ[st] = w.GZ[st]; d.GHID[st] = w.GHID[st]; d.MK[st] = w.MK[st]; }
     d.g_emb = g_embedding;
-    d.ablate = getenv("ED3DGS_FB_ABLATE") ? atoi(getenv("ED3DGS_FB_ABLATE")) : 0;
+    d.ablate = opt(OPT_FB_ABLATE);
     d.store_gz = 1;
     if (!cfg->use_stage[0] && !cfg->use_stage[1]) {
         if (!check_hip(hipMemsetAsync(g_embedding, 0, (size_t)cfg->P * cfg->E * sizeof(float), s), "memset g_emb")) return ED3DGS_ERR_HIP;
         return 0;
     }
-    if (d.NT <= 4 && getenv("ED3DGS_DEFORM_FUSED_BWD")) {
+    if (deep) {
+        // (the layer-by-layer path above has produced every per-Gaussian gradient; the frame backward below is shared)
+    } else if (d.NT <= 4 && opt(OPT_DEFORM_FUSED_BWD)) {
         // EXPERIMENTAL fused path (opt-in): weight gradients accumulated on chip, only g_a partials ([5][P][W] per
         // stage, aliased onto the generic path's ZR region) round-trip HBM.  Parity-green, 3x less HBM traffic, but at
         // one wave per SIMD (135 KB of LDS per block) it is MFMA-busy only 32 % of the time and currently slower
@@ -4345,9 +4353,9 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     } else {
         const int nstrips = (cfg->P + 31) / 32;
         const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
-        const bool piped = d.NT <= 4 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_NO_PIPE");
+        const bool piped = d.NT <= 4 && cfg->E == 32 && !opt(OPT_DEFORM_NO_PIPE);
         // head jobs (g_z re-formed inside the weight-gradient kernel): width 128, head outputs <= 48
-        const bool head_jobs = piped && cfg->W == HJ_W && 3 * cfg->n_sh <= 48 && !getenv("ED3DGS_DEFORM_GENERIC_WGRAD");
+        const bool head_jobs = piped && cfg->W == HJ_W && 3 * cfg->n_sh <= 48 && !opt(OPT_DEFORM_GENERIC_WGRAD);
         d.store_gz = head_jobs ? 0 : 1;
         bool okp = true;
         const bool pd = prof_start(ED3DGS_PROF_DEFORM_DGRAD, s);
@@ -4358,7 +4366,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                     const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
                     const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
                     d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
-                    d.no_tail = getenv("ED3DGS_DEFORM_NO_TAIL") ? 1 : 0;
+                    d.no_tail = opt(OPT_DEFORM_NO_TAIL) ? 1 : 0;
                     d.tail_split = (d.rem_units > 0 && cfg->use_stage[0] && cfg->use_stage[1] && d.rem_units * 2 <= G &&
                                     !d.no_tail) ? 1 : 0;
                     if (d.tail_split && !tail_zeroed) {   // the tail groups' rows of dL/d embedding are accumulated by two units each
@@ -4402,7 +4410,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 }
         };
         const bool both = cfg->use_stage[0] && cfg->use_stage[1];
-        const bool dw1_stream = cfg->W == 128 && cfg->E == 32 && !getenv("ED3DGS_DEFORM_DW1_GENERIC");
+        const bool dw1_stream = cfg->W == 128 && cfg->E == 32 && !opt(OPT_DEFORM_DW1_GENERIC);
         Dw1Args dw1;
         std::memset(&dw1, 0, sizeof dw1);
         dw1.P = cfg->P;
@@ -4498,12 +4506,12 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const bool b3 = use_b3(cfg);
         const int sub = wide ? ED3DGS_PROF_DEFORM_WGRAD_WIDE : ED3DGS_PROF_DEFORM_WGRAD_NARROW;
         const bool ps = prof_start(sub, s);
-        const bool tr_form = fwd_pieces(cfg) == 3 && !getenv("ED3DGS_DEFORM_WGRAD_R1") && cfg->P < (1 << 23);   // 32-bit element offsets in these kernels   // round-2 kernels (exact three-piece mode)
+        const bool tr_form = fwd_pieces(cfg) == 3 && !opt(OPT_DEFORM_WGRAD_R1) && cfg->P < (1 << 23);   // 32-bit element offsets in these kernels   // round-2 kernels (exact three-piece mode)
         if (tr_form) {
             static unsigned long long *wg_timing = nullptr;
-            if (getenv("ED3DGS_WG_TIMING") && !wg_timing) (void)hipMalloc((void **)&wg_timing, 2 * 32 * sizeof(unsigned long long));
-            ha.timing = getenv("ED3DGS_WG_TIMING") ? wg_timing + 32 * wide : nullptr;
-            ha.ablate = getenv("ED3DGS_WG_ABLATE") ? atoi(getenv("ED3DGS_WG_ABLATE")) : 0;
+            if (opt(OPT_WG_TIMING) && !wg_timing) (void)hipMalloc((void **)&wg_timing, 2 * 32 * sizeof(unsigned long long));
+            ha.timing = opt(OPT_WG_TIMING) ? wg_timing + 32 * wide : nullptr;
+            ha.ablate = opt(OPT_WG_ABLATE);
             if (wide) hipLaunchKernelGGL(deform_head_wgrad_tr_kernel<true>, dim3(nblk), dim3(256), 0, s, ha);   // static LDS: 80 KB / 74 KB
             else hipLaunchKernelGGL(deform_head_wgrad_tr_kernel<false>, dim3(nblk), dim3(256), 0, s, ha);
             if (ha.timing) {   // diagnostic: phase cycle sums of block 0 (0 S1 wait, 1 store_g + split, 2 S2 wait, 3 DMA issue, 4 g_z, 5 dW2, 6 dW3)

@@ -1002,14 +1002,26 @@ void launch_identify_tile_ranges(int R, const uint32_t *tile_keys, uint32_t *ran
 static bool bin_two_level(int gx, int gy)
 {
     const int sgx = (gx + 7) >> 3, sgy = (gy + 7) >> 3;
-    return gx < 256 && gy < 256 && sgx * sgy <= 1024 && !getenv("ED3DGS_BIN_ONE_LEVEL");
+    return gx < 256 && gy < 256 && sgx * sgy <= 1024 && !opt(OPT_BIN_ONE_LEVEL);
 }
 
-size_t bin_transpose_bytes(int P, int W, int H, int R)   // scratch behind the binning state, or 0 when the tile counters do not fit in LDS
+// Which form of the stable transpose a frame takes.  The two-level form keeps S <= 1024 super-tile counters in LDS whatever
+// the tile count; only the ONE-level form keeps T tile counters there (two words per tile in bin_scatter_kernel: 96 KB at 48 KB
+// of counters) and is therefore limited to T <= 12288.
+int bin_transpose_level(int P, int W, int H)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
-    if ((size_t)T * sizeof(uint32_t) > 48 * 1024 || P <= 0) return 0;
-    if (bin_two_level(gx, gy)) {
+    if (P <= 0) return 0;
+    if (bin_two_level(gx, gy)) return 2;
+    return (size_t)T * sizeof(uint32_t) <= 48 * 1024 ? 1 : 0;
+}
+
+size_t bin_transpose_bytes(int P, int W, int H, int R)   // scratch behind the binning state, or 0 when neither transpose form fits
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+    const int level = bin_transpose_level(P, W, H);
+    if (level == 0) return 0;
+    if (level == 2) {
         const size_t S = (size_t)((gx + 7) >> 3) * ((gy + 7) >> 3), BA = ((size_t)P + A_ROWS - 1) / A_ROWS;
         const size_t maxseg = (size_t)(R > 0 ? R : 0) / B_SEG + S + 1;
         return (BA * S + 2 * (S + 1) + maxseg * 64 + (size_t)T) * sizeof(uint32_t) + 1024;
@@ -1037,8 +1049,8 @@ void launch_bin_transpose(int P, int W, int H, int R, const GeometryState &g, co
         const size_t ldsA = ((size_t)18 * b.S + 32) * sizeof(uint32_t);
         if (ldsA > 64 * 1024) (void)hipFuncSetAttribute((const void *)bin2_scatterA_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
         static unsigned long long *t2buf = nullptr;
-        if (getenv("ED3DGS_BIN_TIMING") && !t2buf) (void)hipMalloc((void **)&t2buf, 16 * sizeof(unsigned long long));
-        unsigned long long *t2 = getenv("ED3DGS_BIN_TIMING") ? t2buf : nullptr;
+        if (opt(OPT_BIN_TIMING) && !t2buf) (void)hipMalloc((void **)&t2buf, 16 * sizeof(unsigned long long));
+        unsigned long long *t2 = opt(OPT_BIN_TIMING) ? t2buf : nullptr;
         hipLaunchKernelGGL(bin2_scatterA_kernel, dim3(b.BA), dim3(1024), ldsA, s, P, g.rec, g.order, radii, gx, gy, b, t2);
         const int gridB = std::min(b.maxseg, 4096);   // blocks walk the segments (their number is known on the device only)
         hipLaunchKernelGGL(bin2_countB_kernel, dim3(gridB), dim3(256), 0, s, gx, gy, b);
@@ -1060,8 +1072,8 @@ void launch_bin_transpose(int P, int W, int H, int R, const GeometryState &g, co
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64), 0, s, B, T, C, total);   // one wave per block: 128 CUs busy instead of 32
     hipLaunchKernelGGL(bin_tiles_kernel, dim3(1), dim3(1024), 0, s, T, total, reinterpret_cast<uint2 *>(ranges), tile_order);
     static unsigned long long *bin_timing_buf = nullptr;
-    if (getenv("ED3DGS_BIN_TIMING") && !bin_timing_buf) (void)hipMalloc((void **)&bin_timing_buf, 8 * sizeof(unsigned long long));
-    unsigned long long *bin_timing = getenv("ED3DGS_BIN_TIMING") ? bin_timing_buf : nullptr;
+    if (opt(OPT_BIN_TIMING) && !bin_timing_buf) (void)hipMalloc((void **)&bin_timing_buf, 8 * sizeof(unsigned long long));
+    unsigned long long *bin_timing = opt(OPT_BIN_TIMING) ? bin_timing_buf : nullptr;
     // cursors + the per-wave rank fields: 2 T words (65 KB at 1080p); above the default 64 KB the limit has to be raised
     if (2 * lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(B), dim3(256), 2 * lds, s, P, T, g.rec, g.order, radii, gx, gy, C,

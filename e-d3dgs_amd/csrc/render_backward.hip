@@ -86,11 +86,14 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dmdepth, const float *__restrict__ dL_dalpha,
     const float *__restrict__ dL_dnormal, float *__restrict__ grec, float *__restrict__ grec_coord,
     unsigned long long *__restrict__ counters)   // measurement only (bench.py): [0] visited (tile, Gaussian) iterations, [1] blended
-                                                  // pairs, [2] staged list entries, [3] entries kept by the tile-level reject; NULL = off
+                                                  // pairs, [2] staged list entries, [3] entries kept by the tile-level reject,
+                                                  // [4..7] visited iterations whose blended pixels lie in 1 / 2 / 3 / 4 of the tile's
+                                                  // 8x8 quadrants, [8] / [9] sums over visited iterations of the 16x8 (top / bottom)
+                                                  // and 8x16 (left / right) halves with a blended pixel; NULL = off
 {
     constexpr bool GEO = COORD || DEPTH;
     constexpr int NV = COORD ? 32 : 16;
-    unsigned n_iter = 0, n_pair = 0, n_staged = 0, n_kept = 0;
+    unsigned n_iter = 0, n_pair = 0, n_staged = 0, n_kept = 0, n_quad[4] = {0, 0, 0, 0}, n_tb = 0, n_lr = 0;
     __shared__ float4 s_rec[64 * 4];
     __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
     __shared__ uint32_t s_id[64];
@@ -279,6 +282,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             if (counters) {   // per lane; summed over the wave once, at the end of the tile
                 n_iter++;
                 n_pair += (alpha[0] > 0.f) + (alpha[1] > 0.f) + (alpha[2] > 0.f) + (alpha[3] > 0.f);
+                // quadrant of a lane's pixels: x half = bit 1 of the lane (lanes 4 m + {0,1} own columns 0..7), y half = bit 5
+                const unsigned long long bal = __ballot(any_valid);
+                const unsigned long long LEFT = 0x3333333333333333ull, TOP = 0x00000000FFFFFFFFull;
+                const int q00 = (bal & LEFT & TOP) != 0, q10 = (bal & ~LEFT & TOP) != 0, q01 = (bal & LEFT & ~TOP) != 0, q11 = (bal & ~LEFT & ~TOP) != 0;
+                n_quad[q00 + q10 + q01 + q11 - 1]++;
+                n_tb += (q00 | q10) + (q01 | q11);
+                n_lr += (q00 | q01) + (q10 | q11);
             }
 
             const float4 r2 = s_rec[j * 4 + 2];  // b, tongue, ts, rpx
@@ -406,6 +416,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     if (counters && lane == 0) {
         atomicAdd(counters + 0, (unsigned long long)n_iter); atomicAdd(counters + 1, (unsigned long long)n_pair);
         atomicAdd(counters + 2, (unsigned long long)n_staged); atomicAdd(counters + 3, (unsigned long long)n_kept);
+        for (int q = 0; q < 4; q++) atomicAdd(counters + 4 + q, (unsigned long long)n_quad[q]);
+        atomicAdd(counters + 8, (unsigned long long)n_tb); atomicAdd(counters + 9, (unsigned long long)n_lr);
     }
 }
 

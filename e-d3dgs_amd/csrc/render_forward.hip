@@ -16,9 +16,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
     float *__restrict__ out_mcoord, float *__restrict__ out_depth, float *__restrict__ out_mdepth,
     float *__restrict__ out_alpha, float *__restrict__ out_tongue, float *__restrict__ out_normal,
     uint32_t *__restrict__ n_contrib, float *__restrict__ accum_coord, float *__restrict__ accum_depth,
-    float *__restrict__ normal_length)
+    float *__restrict__ normal_length,
+    unsigned long long *__restrict__ counters)   // measurement only (bench.py): [12] visited (tile, Gaussian) iterations, [13] blended
+                                                  // pairs, [14] staged list entries, [15] entries kept by the tile-level reject; NULL = off
 {
     constexpr bool GEO = COORD || DEPTH;
+    unsigned n_iter = 0, n_pair = 0, n_staged = 0, n_kept = 0;
     __shared__ float4 s_rec[64 * 4];
     __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
 
@@ -78,6 +81,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
         __syncthreads();
         // entries that cannot reach alpha >= 1/255 anywhere in the tile are never visited (raster_common.h)
         unsigned long long live = __ballot(keep);
+        if (counters) { n_staged += (unsigned)min(64, n - base); n_kept += (unsigned)__popcll(live); }
         while (live) {
             const int j = __builtin_ctzll(live);
             live &= live - 1;
@@ -99,6 +103,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
                 any_valid |= valid[p];
             }
             if (!__any(any_valid)) continue;
+            if (counters) { n_iter++; n_pair += (unsigned)valid[0] + valid[1] + valid[2] + valid[3]; }
 
             const float4 r2 = s_rec[j * 4 + 2];  // b, tongue, ts, rpx
             float4 r3 = make_float4(0, 0, 0, 0); // rpy, nx, ny, nz
@@ -146,6 +151,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
         }
     }
 
+    if (counters) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n_pair += (unsigned)__shfl_xor((int)n_pair, off);
+        if (lane == 0) {
+            atomicAdd(counters + 12, (unsigned long long)n_iter); atomicAdd(counters + 13, (unsigned long long)n_pair);
+            atomicAdd(counters + 14, (unsigned long long)n_staged); atomicAdd(counters + 15, (unsigned long long)n_kept);
+        }
+    }
     if (nvalid == 0) return;
     const size_t pix0 = (size_t)py * W + px0;
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
@@ -217,7 +230,7 @@ void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t 
                            const float *rec_coord, float focal_x, float focal_y, const float *bg, bool coord,
                            bool depth, float *out_color, float *out_coord, float *out_mcoord, float *out_depth,
                            float *out_mdepth, float *out_alpha, float *out_tongue, float *out_normal, ImageState img,
-                           hipStream_t s)
+                           hipStream_t s, unsigned long long *counters)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     dim3 grid(gx * gy), block(64);
@@ -226,7 +239,7 @@ void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t 
                        reinterpret_cast<const uint2 *>(ranges), point_list, reinterpret_cast<const float4 *>(rec),  \
                        reinterpret_cast<const float4 *>(rec_coord), focal_x, focal_y, bg, out_color, out_coord,      \
                        out_mcoord, out_depth, out_mdepth, out_alpha, out_tongue, out_normal, img.n_contrib,          \
-                       img.accum_coord, img.accum_depth, img.normal_length)
+                       img.accum_coord, img.accum_depth, img.normal_length, counters)
     // variant dispatch as CR/forward.cu:863-870 (NORMAL on iff COORD or DEPTH)
     if (coord && depth) ED3_FWD(true, true);
     else if (coord) ED3_FWD(true, false);

@@ -38,10 +38,13 @@ __global__ void __launch_bounds__(256) image_stats_kernel(const float *__restric
     if ((threadIdx.x & 63) == 0) { part[0][wave] = s0; part[1][wave] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(acc + 0, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(acc + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
-        // no fence between the sums and the ticket: the three words share a cache line (one L2 channel, served in order), and a
-        // device-scope release would write back the XCD's whole L2 -- the price of one per block
+        // RETURNING atomics, their results consumed before the ticket is taken: an atomic's result is back only once the add has
+        // been performed at the memory side, so the ticket cannot overtake a sum (as deform_active_rows_body orders its
+        // counters).  No fence: a device-scope release would write back the XCD's whole L2 -- the price of one per block -- and
+        // nothing here is a plain store another block reads.
+        const float r0 = atomicAdd(acc + 0, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        const float r1 = atomicAdd(acc + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        asm volatile("" :: "v"(r0), "v"(r1) : "memory");   // both results are in registers here (s_waitcnt vmcnt(0) precedes this point)
         const unsigned done = atomicAdd(reinterpret_cast<unsigned *>(acc + 2), 1u);
         last = done == gridDim.x - 1;
         if (last) {
@@ -62,7 +65,7 @@ extern "C" int ed3dgs_image_stats(const float *image, const float *weight, size_
 {
     if (!image || !weight || !acc || !out3 || n == 0) { set_error("ed3dgs_image_stats: null pointer or empty image"); return ED3DGS_ERR_INVALID; }
     if (((uintptr_t)image | (uintptr_t)weight) & 15) { set_error("ed3dgs_image_stats: image / weight must be 16-byte aligned"); return ED3DGS_ERR_INVALID; }
-    const int blocks = (int)std::min<size_t>(getenv("ED3DGS_STATS_BLOCKS") ? atoi(getenv("ED3DGS_STATS_BLOCKS")) : 256, (n / 4 + 1023) / 1024 + 1);   // few blocks: three same-line atomics per block serialise (512 blocks: 28 us, 256: 20 us)
+    const int blocks = (int)std::min<size_t>(opt(OPT_STATS_BLOCKS) > 0 ? opt(OPT_STATS_BLOCKS) : 256, (n / 4 + 1023) / 1024 + 1);   // few blocks: three same-line atomics per block serialise (512 blocks: 28 us, 256: 20 us)
     hipLaunchKernelGGL(image_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, weight, n, mid, acc, out3);
     return check_hip(hipGetLastError(), "image_stats") ? 0 : ED3DGS_ERR_HIP;
 }

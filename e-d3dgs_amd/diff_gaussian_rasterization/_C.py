@@ -85,8 +85,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scal
             return torch.empty((c, H, W), **fopt)
         if run:
             # a plane the variant does not produce (the reference returns freshly filled zeros: 25 MB and a launch each at
-            # 1080p): one zero (per device, made once) expanded to the shape.  Reads as zeros everywhere; an in-place write raises
-            # instead of aliasing.
+            # 1080p): one zero (per device, made once) expanded to the shape.  READ-ONLY: reads as zeros everywhere, an in-place
+            # write raises instead of aliasing; the library gets NULL for it, never the shared 4 bytes.
             z = _ZERO.get(dev)
             if z is None:
                 z = _ZERO[dev] = torch.zeros((), **fopt)
@@ -108,8 +108,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scal
             _ptr(tongue_class), _ptr(scales), C.c_float(_num(scale_modifier, float)), _ptr(rotations),
             _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), C.c_float(_num(tan_fovx, float)),
             C.c_float(_num(tan_fovy, float)), C.c_float(_num(kernel_size, float)), C.c_int(bool(prefiltered)),
-            _ptr(out_color), _ptr(out_coord), _ptr(out_mcoord), _ptr(out_depth), _ptr(out_mdepth), _ptr(out_alpha),
-            _ptr(out_tongue), _ptr(out_normal), _ptr(radii), C.c_int(rc), C.c_int(rd), C.c_int(bool(debug)), _stream())
+            _ptr(out_color), _ptr(out_coord) if rc else None, _ptr(out_mcoord) if rc else None,
+            _ptr(out_depth) if rd else None, _ptr(out_mdepth) if rd else None, _ptr(out_alpha),
+            _ptr(out_tongue), _ptr(out_normal) if geo else None, _ptr(radii), C.c_int(rc), C.c_int(rd), C.c_int(bool(debug)), _stream())
         if rendered < 0:
             raise RuntimeError(_lib.last_error())
     if KEEP_LAST:
@@ -131,11 +132,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     rotations = _f32c(rotations, "rotations"); cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp")
     sh = _f32c(sh, "sh"); background = _f32c(background, "bg"); viewmatrix = _f32c(viewmatrix, "viewmatrix")
     projmatrix = _f32c(projmatrix, "projmatrix"); campos = _f32c(campos, "campos")
-    grads = [_f32c(g, "grad") for g in (dL_dout_color, dL_dout_coord, dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth,
-                                        dL_dout_alpha, dL_dout_normal)]
-    normalmap = _f32c(normalmap, "normalmap"); alphas = _f32c(alphas, "alphas")
-    M = sh.size(1) if sh.numel() else 0
     rc, rd = bool(require_coord), bool(require_depth)
+    geo = rc or rd
+    # planes the variant does not produce have no upstream gradient the kernels read: NULL for the library, and no
+    # .contiguous() copy of an expanded zero plane (3 x H x W floats for the normal map)
+    used = (True, rc, rc, rd, rd, True, geo)
+    grads = [_f32c(g, "grad") if u else None for g, u in zip((dL_dout_color, dL_dout_coord, dL_dout_mcoord, dL_dout_depth,
+                                                              dL_dout_mdepth, dL_dout_alpha, dL_dout_normal), used)]
+    normalmap = _f32c(normalmap, "normalmap") if geo else None
+    alphas = _f32c(alphas, "alphas")
+    M = sh.size(1) if sh.numel() else 0
     fopt = dict(dtype=torch.float32, device=dev)
     run = P != 0
     new = torch.empty if run else torch.zeros

@@ -52,8 +52,11 @@ def lib():
         getattr(L, n).restype = C.c_size_t
     for n in ("ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible", "ed3dgs_state_view_get",
               "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
-              "ed3dgs_activations_backward", "ed3dgs_compute_3d_filter", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts"):
+              "ed3dgs_activations_backward", "ed3dgs_compute_3d_filter", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts",
+              "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts"):
         getattr(L, n).restype = C.c_int
+    L.ed3dgs_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.ed3dgs_get_option.argtypes = [C.c_char_p]
     _lib = L
     return L
 
@@ -65,7 +68,37 @@ EXPORTS = (
     "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
     "ed3dgs_activations_backward", "ed3dgs_filter3d_workspace_bytes", "ed3dgs_compute_3d_filter",
     "ed3dgs_knn_workspace_bytes", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours",
-    "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts")
+    "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts",
+    "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts")
+
+
+def set_option(name, value):
+    """Set a process-wide switch of the library (include/ed3dgs.h: ed3dgs_set_option); returns the previous value."""
+    old = lib().ed3dgs_set_option(name.encode(), int(value))
+    if old < 0 and last_error().startswith("ed3dgs_set_option"):
+        raise KeyError(last_error())
+    return old
+
+
+def get_option(name):
+    return lib().ed3dgs_get_option(name.encode())
+
+
+class options:
+    """Context manager: switches set on entry, restored on exit (tests, bench A/B passes)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def last_error():

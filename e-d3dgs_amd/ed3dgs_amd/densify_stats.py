@@ -6,9 +6,20 @@ into per-Gaussian accumulators (train.py:404-407 -> GaussianModel.add_densificat
 (scene/gaussian_model.py:452-514).  With frames sharded over ranks each rank sees only its own views, so the accumulators
 are per-rank partial sums: before a decision they are combined over ranks -- SUM for `xyz_gradient_accum` / the abs-grad
 accumulator (the `.z` column of dL_dmeans2D) / `denom`, MAX for `max_radii2D` -- in TWO collectives (one flat
-fp32 SUM buffer of 3P floats, one MAX of P), after which every rank holds the statistics a single-GPU run over the union of
-the views would hold and takes bit-identical decisions.  The split's random offsets come from a generator seeded by the
-iteration number, identical on every rank, so the post-densify tensors are identical too (checked by hash in the tests).
+fp32 SUM buffer of 3P floats, one MAX of P), after which every rank holds the statistics a single-GPU run with
+batch_size = 1 over the union of the views would hold -- one add() per view -- and takes bit-identical decisions.  The
+split's random offsets come from a generator seeded by the iteration number, identical on every rank, so the post-densify
+tensors are identical too (checked by hash in the tests).
+
+Which single-GPU run that is matters.  N data-parallel ranks that take ONE optimizer step together correspond to the
+reference's batch_size = N, and for a batch the reference first sums the views' RAW screen-space gradients (train.py:346-348),
+ORs their visibility (train.py:190), maxes their radii (:189) and then calls add_densification_stats ONCE: ||sum_v g_v|| is
+added and denom grows by 1 (scene/gaussian_model.py:516-518) -- whereas add() per view accumulates sum_v ||g_v|| and
+denom += (views that see the Gaussian).  The mean gradient compared with densify_grad_threshold differs between the two (by
+up to a factor N), so clone / split decisions differ.  Both are offered: add() + all_reduce_() = sequential batch_size-1
+iterations over the union of the views; add_batched_step() = the reference's batched step (three collectives per step,
+accumulators replicated, no all_reduce_() before the decision).  tests/test_densify_stats_cpu.py pins each against the
+reference's formulas.
 
 Only what the decision needs is here; the optimizer-state surgery of cat_tensors_to_optimizer / _prune_optimizer
 (scene/gaussian_model.py:364-423) stays with the caller's optimizer, as SURVEY section 2 scopes it.
@@ -34,6 +45,7 @@ class DensificationStats:
         self.denom = z(num_points, 1)
         self.max_radii2D = z(num_points)
         self._reduced = False
+        self._replicated = False
 
     @torch.no_grad()
     def add(self, viewspace_point_grad, visibility_filter, radii):
@@ -48,9 +60,37 @@ class DensificationStats:
         self.denom[vf] += 1
 
     @torch.no_grad()
+    def add_batched_step(self, viewspace_point_grad, visibility_filter, radii):
+        """One optimizer step taken by all ranks together = ONE batch of the reference (train.py:166-190, 346-348, 404-407):
+        SUM the ranks' raw (P, 3) screen-space gradients, OR their visibility, MAX their radii, then one
+        add_densification_stats.  Every rank ends with identical accumulators; do not call all_reduce_() afterwards."""
+        if self._reduced:
+            raise RuntimeError("DensificationStats.add_batched_step after all_reduce_: call reset() first")
+        g = viewspace_point_grad.detach().clone()
+        vis = visibility_filter.to(torch.float32)
+        rad = radii.to(self.max_radii2D.dtype).clone()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            wg, wv, wr = D._on_wire(g), D._on_wire(vis), D._on_wire(rad)
+            works = [dist.all_reduce(wg, op=dist.ReduceOp.SUM, async_op=True), dist.all_reduce(wv, op=dist.ReduceOp.MAX, async_op=True),
+                     dist.all_reduce(wr, op=dist.ReduceOp.MAX, async_op=True)]
+            for w in works:
+                w.wait()
+            for dst, src in ((g, wg), (vis, wv), (rad, wr)):
+                if src is not dst:
+                    dst.copy_(src)
+        vf = vis > 0
+        self.max_radii2D[vf] = torch.max(self.max_radii2D[vf], rad[vf])
+        self.xyz_gradient_accum[vf] += torch.norm(g[vf, :2], dim=-1, keepdim=True)
+        self.abs_gradient_accum[vf] += g[vf, 2:3]
+        self.denom[vf] += 1
+        self._replicated = True
+
+    @torch.no_grad()
     def all_reduce_(self):
         """Combine the ranks' partial statistics in place: one SUM over a flat (3P) buffer, one MAX over (P).  RCCL on
         the GPUs (device buffers, in place); gloo on the CPU tests."""
+        if getattr(self, "_replicated", False):
+            raise RuntimeError("DensificationStats.all_reduce_ after add_batched_step: the accumulators are already replicated")
         if dist.is_initialized() and dist.get_world_size() > 1:
             P = self.denom.shape[0]
             flat = torch.cat((self.xyz_gradient_accum.reshape(-1), self.abs_gradient_accum.reshape(-1), self.denom.reshape(-1)))

@@ -81,6 +81,40 @@ def item_of(index, n_cams, n_frames):
     return (index // n_frames) % n_cams, index % n_frames
 
 
+def visit_stride(n):
+    """A stride coprime to n, near 0.37 n: k -> (k * stride) % n visits every index once per n steps and spreads any short
+    run of steps over the whole list (a 20-step run over 8 cameras x 50 frames, frames fastest, sees all 8 cameras)."""
+    from math import gcd
+    if n <= 2:
+        return 1
+    s = max(1, int(round(0.37 * n)))
+    while gcd(s, n) != 1:
+        s += 1
+    return s
+
+
+def strided_item(my_items, k):
+    """The k-th item a rank renders: its shard visited with visit_stride (train.py:134-187 draws items at random; a fixed
+    coprime stride is the deterministic stand-in)."""
+    n = len(my_items)
+    return my_items[(k * visit_stride(n)) % n]
+
+
+def gather_per_rank(value, device):
+    """[value of rank 0, ..., value of rank N-1] on every rank (one SUM all-reduce of a one-hot vector)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    t = torch.zeros(world, dtype=torch.float64 if device == "cpu" else torch.float32, device=device)
+    t[rank] = float(value)
+    allreduce_sum_(t)
+    return [float(x) for x in t.tolist()]
+
+
+def destroy():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def allreduce_stats(loss_sum, psnr_sum, count, device):
     """The path's single collective: SUM of [loss, psnr, count] over ranks.  Returns a tensor of 3 floats."""
     t = torch.tensor([float(loss_sum), float(psnr_sum), float(count)], dtype=torch.float64 if device == "cpu" else torch.float32, device=device)
@@ -143,3 +177,77 @@ def allreduce_gradients_(params, bucket_bytes=64 << 20, average=True):
             else:
                 p.grad.copy_(g)
             off += n
+
+
+class BucketedGradReducer:
+    """allreduce_gradients_ driven by autograd: every parameter gets a post-accumulate hook, and a bucket's all-reduce is issued
+    the moment its last gradient has landed -- while the backward is still producing the others -- instead of after
+    backward() has returned.  finish() waits for the buckets, averages and writes the results back into .grad.  Parameters
+    that received no gradient by finish() contribute zeros (every rank must issue the same collectives in the same order:
+    buckets are therefore ISSUED in bucket order; one that fills early waits for its predecessors).
+    In render()'s graph the deformation node delivers most leaf gradients together at the very end, so what overlaps is the
+    packing of bucket k+1 with the transfer of bucket k and the early SH / opacity gradients with the MLP backward."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in self.params:
+            nb = p.numel() * p.element_size()
+            if cur and (cur_bytes + nb > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self.buckets.append(cur); cur, cur_bytes = [], 0
+            cur.append(p); cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.missing = [len(b) for b in self.buckets]
+        self.pending = [None] * len(self.buckets)
+        self.next_issue = 0
+        self.handles = [p.register_post_accumulate_grad_hook(self._landed) for p in self.params]
+        self.issued_in_backward = 0
+
+    def _issue_ready(self, force=False):
+        while self.next_issue < len(self.buckets) and (force or self.missing[self.next_issue] == 0):
+            i = self.next_issue
+            b = self.buckets[i]
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+            wire = _on_wire(flat)
+            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True) if (dist.is_initialized() and dist.get_world_size() > 1) else None
+            self.pending[i] = (flat, wire, work)
+            self.next_issue += 1
+            if not force:
+                self.issued_in_backward += 1
+
+    def _landed(self, p):
+        i = self.bucket_of[id(p)]
+        self.missing[i] -= 1
+        self._issue_ready()
+
+    def finish(self):
+        """Issue what is left (parameters without a gradient count as zeros), wait, average, write back; re-arm."""
+        self._issue_ready(force=True)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        for b, (flat, wire, work) in zip(self.buckets, self.pending):
+            if work is not None:
+                work.wait()
+            if wire is not flat:
+                flat.copy_(wire)
+            if self.average and world > 1:
+                flat.div_(world)
+            off = 0
+            for p in b:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        self.missing = [len(b) for b in self.buckets]
+        self.pending = [None] * len(self.buckets)
+        self.next_issue = 0
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []

@@ -186,9 +186,10 @@ class deform_network(nn.Module):
 
     # ---- helpers of the fused path ----
     def _stage_parts(self, s):
-        """The stage's 22 parameters in packed order.  The Linear modules are looked up once (nn.Sequential indexing is slow)
-        and re-checked by identity against the module tree on every call; their parameters are read from the modules on every
-        call, so a replaced module or Parameter is seen."""
+        """The stage's 22 parameters in packed order (+ 2 per extra trunk layer when defor_depth > 1, appended at the end:
+        include/ed3dgs.h).  The Linear modules are looked up once (nn.Sequential indexing is slow) and re-checked by identity
+        against the module tree on every call; their parameters are read from the modules on every call, so a replaced module
+        or Parameter is seen."""
         cache = self.__dict__.setdefault("_stage_linears", {})
         ent = cache.get(s)
         mods = self._modules
@@ -202,6 +203,9 @@ class deform_network(nn.Module):
             for h in HEADS:
                 seq = mods[f"{h}_deform_{s}"]
                 ent += [(f"{h}_deform_{s}", "1", seq, seq[1]), (f"{h}_deform_{s}", "3", seq, seq[3])]
+            trunk = mods[f"feature_out_{s}"]
+            for i in range(max(self.D - 1, 0)):   # feature_out.{2, 4, ..} (scene/deformation.py:38-44)
+                ent.append((f"feature_out_{s}", str(2 * (i + 1)), trunk, trunk[2 * (i + 1)]))
             cache[s] = ent
         parts = []
         for _, _, _, m in ent:
@@ -214,7 +218,9 @@ class deform_network(nn.Module):
         call after something re-bound a parameter's storage: .to(), a replaced Parameter) packs them once into one flat buffer
         and points every parameter's .data at its slice of it, so in-place updates (optimizer steps, load_state_dict) keep the
         packed block current.  Names, shapes and state-dict contents are untouched.  With autograd on, a view node routes the
-        packed gradient back to the parameters as slices (no copies either way)."""
+        packed gradient back to the parameters as slices (no copies either way).  Visible side effects:
+        the 22 parameters of a stage alias ONE storage (torch.save of a single parameter serialises the whole block; state_dict()
+        round-trips unchanged), their .grad tensors are views of one packed gradient, and non-fp32 parameters are refused."""
         parts = self._stage_parts(s)
         store = self.__dict__.setdefault("_flat_store", {})
         flat = store.get(s)
@@ -228,8 +234,12 @@ class deform_network(nn.Module):
                 off += p.numel()
             ok = ok and off == flat.numel()
         if not ok:
+            bad = [tuple(p.shape) for p in parts if p.dtype != torch.float32]
+            if bad:   # re-binding .data to an fp32 slice would silently change the parameter's dtype
+                raise TypeError("deform_network: the fused MI355X path computes in fp32 and packs the Linear parameters in place; "
+                                f"found non-fp32 parameters of shapes {bad[:3]} -- keep the module in float32 (.float())")
             with torch.no_grad():
-                flat = torch.cat([p.detach().reshape(-1).float() for p in parts])
+                flat = torch.cat([p.detach().reshape(-1) for p in parts])
                 off = 0
                 for p in parts:
                     p.data = flat[off:off + p.numel()].view(p.shape)
@@ -259,8 +269,6 @@ class deform_network(nn.Module):
         gradients, so neither the concatenation nor autograd's two slice copies run.  The last element of the returned
         `orig` tuple is then the pair (sh_coefs, sh_coefs_rest)."""
         a = self.args
-        if self.D > 1:
-            raise NotImplementedError("defor_depth > 1 is not supported by the fused MI355X deformation path")
         pts, scales, rotations, opacity = point[:, :3], scales[:, :3], rotations[:, :4], opacity[:, :1]
         orig = (pts, scales, rotations, opacity, sh_coefs if sh_coefs_rest is None else (sh_coefs, sh_coefs_rest))
         emb = embeddings if pc is None else pc.get_embedding

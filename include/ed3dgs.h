@@ -40,6 +40,17 @@ typedef char *(*ed3dgs_alloc_fn)(void *user, size_t bytes);
 const char *ed3dgs_last_error(void);
 int ed3dgs_abi_version(void);
 
+/* Process-wide switches (A/B modes and diagnostics; none changes a result beyond the stated tolerances).  Each is read from the
+ * environment ONCE, when the library is loaded (ED3DGS_<NAME>=<int>), and afterwards only changed here; no entry point reads the
+ * environment per call.  `name` with or without the ED3DGS_ prefix.  set returns the previous value; both return
+ * ED3DGS_ERR_INVALID for an unknown name.  Not thread-safe against concurrent calls into the library.
+ * (The reference has no such switches: its modes are compile-time, CR/config.h.) */
+int ed3dgs_set_option(const char *name, int value);
+int ed3dgs_get_option(const char *name);
+/* Which binning back end a frame of this size takes under the current switches: 2 = two-level stable transpose, 1 = one-level
+ * transpose, 0 = scan + K3 + radix sort + K5 (CR/rasterizer_impl.cu:355-395 as written).  For tests and diagnostics. */
+int ed3dgs_binning_path(int P, int width, int height);
+
 /* Sizes of the three opaque state buffers (CR/rasterizer_impl.h:77-95 `required<T>`); layout is private. */
 size_t ed3dgs_geometry_bytes(int P);
 size_t ed3dgs_image_bytes(int width, int height);
@@ -206,6 +217,11 @@ int ed3dgs_profile_begin(int max_samples);
  * slot and ED3DGS_PROF_COUNT_WORK on: out4 = {visited (tile, Gaussian) iterations, blended pixel-Gaussian pairs, list entries staged, entries kept by the
  * tile-level reject}.  Measurement only: bench.py prices K7 against the VALU roof with them. */
 int ed3dgs_profile_tile_backward_counts(unsigned long long out4[4]);
+/* All work counters of the tile kernels (first min(n, ED3DGS_PROF_COUNTERS) of them): [0..3] as above (K7); [4..7] K7's visited
+ * iterations whose blended pixels lie in 1 / 2 / 3 / 4 of the tile's 8x8 quadrants; [8], [9] sums over K7's visited iterations of
+ * the 16x8 (top / bottom) and 8x16 (left / right) tile halves holding a blended pixel; [12..15] K6: visited iterations, blended
+ * pairs, list entries staged, entries kept by the tile-level reject. */
+int ed3dgs_profile_tile_counts(unsigned long long *out, int n);
 int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches);
 /* Same, for every timed kernel: arrays of ED3DGS_PROF_SLOTS entries indexed by the slots below. */
 enum {
@@ -218,6 +234,7 @@ enum {
     ED3DGS_PROF_DEFORM_WGRAD_WIDE = 6,   /* ... the wide (SH) head's launch(es) */
     ED3DGS_PROF_DEFORM_WGRAD_NARROW = 7, /* ... the narrow heads' launch */
     ED3DGS_PROF_SLOTS = 8,
+    ED3DGS_PROF_COUNTERS = 16,      /* length of the tile kernels' work-counter array (ed3dgs_profile_tile_counts) */
     ED3DGS_PROF_COUNT_WORK = 1 << 30   /* flag in the slot mask: also count K7's work (ed3dgs_profile_tile_backward_counts) */
 };
 int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask);  /* bit k = time slot k; every event pair costs
@@ -230,12 +247,15 @@ int ed3dgs_profile_end_slots(double *ms_total, int *launches);
  * (get_temporal_embed :53-67, time offset :112-117) is computed on the device from the table, and the per-Gaussian
  * MLP (trunk Linear over [h_t | embedding], five heads Linear-ReLU-Linear, residual updates :90-106) runs on fp32
  * MFMA with activations resident in registers.  W = net_width (multiple of 32, <= 256), E = gaussian embedding dim
- * (multiple of 32), TD = temporal embedding dim, D = defor_depth (0 or 1: the trunk is one Linear; deeper trunks
- * are rejected with ED3DGS_ERR_INVALID).
- * Packed parameter block of one stage (fp32, state-dict order of scene/deformation.py:38-51):
+ * (multiple of 32), TD = temporal embedding dim, D = defor_depth (0 or 1: the trunk is one Linear -- every configuration
+ * the reference ships; 2..8: (D - 1) further [ReLU, Linear(W, W)] trunk layers, scene/deformation.py:38-44, computed layer by
+ * layer by plain fp32 kernels -- exact, not tuned; E must be 32).
+ * Packed parameter block of one stage (fp32, state-dict order of scene/deformation.py:38-51 except that the extra trunk
+ * layers come LAST, so that every other offset is independent of D):
  *   feature_out.0.weight[W][TD+E], feature_out.0.bias[W],
  *   for head in (pos, scales, rotations, opacity, rgb): {1.weight[W][W], 1.bias[W], 3.weight[n_k][W], 3.bias[n_k]},
- *   n_k = 3, 3, 4, 1, 3*n_sh.
+ *   n_k = 3, 3, 4, 1, 3*n_sh,
+ *   for i in 1 .. D-1: feature_out.(2i).weight[W][W], feature_out.(2i).bias[W].
  */
 typedef struct ed3dgs_deform_cfg {
     int P;               /* Gaussians */

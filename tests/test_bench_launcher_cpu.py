@@ -27,6 +27,20 @@ def test_gpus_2_launches_two_ranks_without_external_torchrun():
     assert d["rehearsal"] is True and d["value"] is None   # never mistakable for a measurement
     assert d["backend"] == "gloo" and d["items_per_rank"] == [6.0, 6.0] and d["last_step_ranks_counted"] == 2.0
     assert d["steps"] == 6 and d["warmup"] == 1
+    # the per-rank fields the real line carries, and the strided item schedule ("tiny": 2 cameras x 4 frames, 4 items per rank)
+    assert len(d["step_ms_median_per_rank"]) == 2 and len(d["mean_num_rendered_per_rank"]) == 2
+    assert len(set(d["rank0_items_timed"][:4])) == 4 and d["rank0_cameras_timed"] == [0, 1] and d["cameras_timed_per_rank"] == [2.0, 2.0]
+
+
+def test_20_steps_of_c3_visit_every_camera_on_every_rank_count():
+    """VERDICT r2 #12: the driver's 20 timed steps of C3 (8 cameras x 50 frames) must not be camera 0 only."""
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "0",
+                            "--workload", "C3", "--rehearse-launcher"], env=_env(), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["rank0_cameras_timed"] == list(range(8)) and d["cameras_timed_per_rank"] == [8.0] * gpus
+        assert len(set(d["rank0_items_timed"])) == 20
 
 
 def test_gpus_must_match_the_torchrun_world():

@@ -17,7 +17,11 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _lists_equal(inp):
+def _lists_equal(inp, path=None):
+    """`path`: the binning back end the frame must take (ed3dgs_binning_path: 2 two-level transpose, 1 one-level, 0 radix)."""
+    if path is not None:
+        from ed3dgs_amd import _lib
+        assert _lib.lib().ed3dgs_binning_path(int(inp["P"]), int(inp["W"]), int(inp["H"])) == path
     fw = util.oracle_forward(inp, "FFF", with_margin=False)
     out, sv = util.hip_forward_raw(inp, "FFF")
     assert out[0] == fw["num_rendered"]
@@ -36,32 +40,42 @@ def _giants(inp, n, factor):
     return inp
 
 
+# case -> (inputs, the back end it must take)
 CASES = {
     # 30 Gaussians 60x larger: their rects cover the whole 120 x 68 tile grid (all 135 super-tiles)
-    "giants-1080p": lambda: _giants(util.scene_inputs(3000, 1920, 1080, scene_seed=5, cam_seed=6), 30, 60.0),
+    "giants-1080p": lambda: (_giants(util.scene_inputs(3000, 1920, 1080, scene_seed=5, cam_seed=6), 30, 60.0), 2),
     # every centre inside a 0.02-wide cube: one or two super-tiles hold all rows (157 segments of one column)
-    "pile": lambda: dict(util.scene_inputs(40000, 800, 608, scene_seed=7, cam_seed=8), means3D=util.scene_inputs(40000, 800, 608, scene_seed=7, cam_seed=8)["means3D"] * 0.01),
-    # 240 x 135 tiles, 30 x 17 = 510 super-tiles (two threads per count column)
-    "4k": lambda: _giants(util.scene_inputs(6000, 3840, 2160, scene_seed=9, cam_seed=10), 5, 40.0),
+    "pile": lambda: (dict(util.scene_inputs(40000, 800, 608, scene_seed=7, cam_seed=8), means3D=util.scene_inputs(40000, 800, 608, scene_seed=7, cam_seed=8)["means3D"] * 0.01), 2),
+    # 240 x 135 tiles = 32400 (more than any LDS counter array of the one-level form), 30 x 17 = 510 super-tiles: two threads
+    # per count column in level A's column sums, 8 blocks of 64 super-tiles per row mask
+    "4k": lambda: (_giants(util.scene_inputs(6000, 3840, 2160, scene_seed=9, cam_seed=10), 5, 40.0), 2),
+    # the same grid with enough rows for several level-A blocks and giants that cover all 510 super-tiles
+    "4k-giants-9k": lambda: (_giants(util.scene_inputs(9000, 3840, 2160, scene_seed=21, cam_seed=22), 12, 80.0), 2),
+    # 128 x 96 tiles = 12288 (the one-level form's limit exactly), 16 x 12 = 192 super-tiles: 5 threads per column, 3 mask blocks
+    "2048x1536": lambda: (_giants(util.scene_inputs(5000, 2048, 1536, scene_seed=23, cam_seed=24), 8, 50.0), 2),
+    # 250 x 250 tiles, 32 x 32 = 1024 super-tiles: the two-level form's limit (one thread per column, 16 mask blocks, 74 KB of LDS)
+    "4000x4000": lambda: (_giants(util.scene_inputs(3000, 4000, 4000, scene_seed=25, cam_seed=26), 4, 60.0), 2),
     # 257 tile columns: past the 8-bit rect of the two-level form -> the one-level transpose
-    "wide-one-level": lambda: util.scene_inputs(4000, 4112, 400, scene_seed=11, cam_seed=12),
+    "wide-one-level": lambda: (util.scene_inputs(4000, 4112, 400, scene_seed=11, cam_seed=12), 1),
+    # 257 x 60 tiles = 15420 > 12288: neither transpose form -> round 1's scan + K3 + radix sort + K5
+    "wide-radix": lambda: (util.scene_inputs(4000, 4112, 960, scene_seed=27, cam_seed=28), 0),
     # one tile, one super-tile
-    "one-tile": lambda: util.scene_inputs(500, 16, 16, scene_seed=13, cam_seed=14),
-    "one-row": lambda: util.scene_inputs(1, 400, 400, scene_seed=15, cam_seed=16),
-    "1025-rows": lambda: util.scene_inputs(1025, 640, 480, scene_seed=17, cam_seed=18),
+    "one-tile": lambda: (util.scene_inputs(500, 16, 16, scene_seed=13, cam_seed=14), 2),
+    "one-row": lambda: (util.scene_inputs(1, 400, 400, scene_seed=15, cam_seed=16), 2),
+    "1025-rows": lambda: (util.scene_inputs(1025, 640, 480, scene_seed=17, cam_seed=18), 2),
 }
 
 
 @pytest.mark.parametrize("case", list(CASES), ids=list(CASES))
 def test_lists_bit_exact(case):
     _need_gpu()
-    fw = _lists_equal(CASES[case]())
+    fw = _lists_equal(*CASES[case]())
     print(case, "instances", fw["num_rendered"], "visible", int((fw["radii"] > 0).sum()))
 
 
-@pytest.mark.parametrize("env", ["ED3DGS_BIN_ONE_LEVEL", "ED3DGS_BIN_RADIX"])
-def test_other_binning_paths_agree(env, monkeypatch):
+@pytest.mark.parametrize("switch,path", [("BIN_ONE_LEVEL", 1), ("BIN_RADIX", 0)])
+def test_other_binning_paths_agree(switch, path, libopt):
     """The one-level transpose and round 1's two-level radix path on a case with giants and a crowded centre."""
     _need_gpu()
-    monkeypatch.setenv(env, "1")
-    _lists_equal(_giants(util.scene_inputs(20000, 1100, 1604, scene_seed=19, cam_seed=20), 10, 30.0))
+    libopt(switch, 1)
+    _lists_equal(_giants(util.scene_inputs(20000, 1100, 1604, scene_seed=19, cam_seed=20), 10, 30.0), path)

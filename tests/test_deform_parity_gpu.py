@@ -54,24 +54,20 @@ def rel(a, b):
 
 @pytest.mark.parametrize("mode", ["exact-split", "split-bf16x3", "fp32-mfma"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
-def test_golden_values_and_grads(path, mode, monkeypatch):
+def test_golden_values_and_grads(path, mode, monkeypatch, libopt):
     """Against the reference's own outputs, tolerance 1e-4, in the three multiply modes of csrc/deform.hip: the default
     (three exact bf16 pieces per fp32 operand, eight products), the f32-operand MFMA kernels (ED3DGS_DEFORM_FP32_MFMA=1)
     and the opt-in reduced two-piece / three-product kernels (ED3DGS_DEFORM_BF16X3=1)."""
     _need_gpu()
-    for v in ("ED3DGS_DEFORM_BF16X3", "ED3DGS_DEFORM_BF16X6", "ED3DGS_DEFORM_FP32_MFMA"):
-        monkeypatch.delenv(v, raising=False)
+    for v in ("DEFORM_BF16X3", "DEFORM_FP32_MFMA"):
+        libopt(v, 0)
     if mode == "split-bf16x3":
-        monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
+        libopt("DEFORM_BF16X3", 1)
     elif mode == "fp32-mfma":
-        monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
+        libopt("DEFORM_FP32_MFMA", 1)
     z, a = _load(path)
-    if int(z["cfg_D"]) > 1:
-        net = _build(z, a)
-        with pytest.raises(NotImplementedError):
-            net(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 4).cuda(), torch.zeros(4, 1).cuda(),
-                0.5, None, _PC(torch.zeros(4, 32).cuda()), None, torch.zeros(4, 16, 3).cuda(), iter=10)
-        return
+    if int(z["cfg_D"]) > 1 and mode != "exact-split":
+        pytest.skip("defor_depth > 1 takes the layer-by-layer fp32 path (csrc/deform_deep.hip) in every multiply mode")
     net = _build(z, a)
     leaf = lambda n: torch.from_numpy(z["in_" + n]).cuda().requires_grad_(True)
     xyz, scales, rot, opacity, sh, emb = [leaf(n) for n in ("xyz", "scales", "rot", "opacity", "sh", "emb")]
@@ -128,7 +124,7 @@ def test_golden_values_and_grads(path, mode, monkeypatch):
         "5k-split-bf16", "tail-split-bf16-no_dr", "w64-split-bf16",
         "5k-fp32-mfma", "5k-stateless-fp32-mfma", "tail-fp32-mfma-no_dr", "w64-fp32-mfma",
         "sparse60", "sparse97-no_dr", "one-active-row", "no-active-row", "sparse60-dense-walk", "sparse60-fine-only"])
-def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
+def test_against_torch_restatement(P, W, keep, flags, monkeypatch, libopt):
     """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
     keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
     _need_gpu()
@@ -139,13 +135,13 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
     monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", keep)
     flags = dict(flags)
     if flags.pop("b3", False):
-        monkeypatch.setenv("ED3DGS_DEFORM_BF16X3", "1")
+        libopt("DEFORM_BF16X3", 1)
     if flags.pop("f32", False):
-        monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
+        libopt("DEFORM_FP32_MFMA", 1)
     sparse = flags.pop("sparse", 0.0)
-    monkeypatch.delenv("ED3DGS_DEFORM_DENSE_BWD", raising=False)
+    libopt("DEFORM_DENSE_BWD", 0)
     if flags.pop("dense_bwd", False):
-        monkeypatch.setenv("ED3DGS_DEFORM_DENSE_BWD", "1")
+        libopt("DEFORM_DENSE_BWD", 1)
     a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
     torch.manual_seed(5)
     net = deform_network(D=1, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
@@ -206,7 +202,7 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch):
 @pytest.mark.parametrize("P,flags,loss_on_sub", [(5000, {}, True), (65836, {}, False), (5000, dict(no_dc=True), True),
                                                  (5000, dict(f32=True), True), (777, dict(stateless=True), True)],
                          ids=["5k", "tail-no-sub-loss", "no_dc", "fp32-mfma", "stateless"])
-def test_split_sh_storage_matches_whole(P, flags, loss_on_sub, monkeypatch):
+def test_split_sh_storage_matches_whole(P, flags, loss_on_sub, monkeypatch, libopt):
     """forward(sh_coefs=_features_dc, sh_coefs_rest=_features_rest) against forward(sh_coefs=cat(dc, rest)): identical
     outputs (bit for bit: the same arithmetic on the same values), dL/d dc and dL/d rest equal to the slices of the whole
     tensor's gradient (bit for bit: g_sh + gs_sh either way), parameter gradients equal up to the order of the atomic sums."""
@@ -216,7 +212,7 @@ def test_split_sh_storage_matches_whole(P, flags, loss_on_sub, monkeypatch):
     from scene.deformation import deform_network
     flags = dict(flags)
     if flags.pop("f32", False):
-        monkeypatch.setenv("ED3DGS_DEFORM_FP32_MFMA", "1")
+        libopt("DEFORM_FP32_MFMA", 1)
     monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", not flags.pop("stateless", False))
     a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
     torch.manual_seed(11)
@@ -325,3 +321,75 @@ def test_fused_activations_match_torch(with_filter):
     ref = [ss.detach(), rr.detach(), oo2.detach(), s2.grad, r2.grad, o2.grad]
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+def test_train_style_steps_match_the_unpacked_module(D):
+    """ADVICE r2 (_flat_stage re-binds every Linear parameter to a slice of one packed buffer): three full train-style steps
+    -- forward, backward, Adam step, zero_grad(set_to_none=False) -- then a state_dict save / load into a fresh module, against
+    the same steps on the float64-free CPU restatement with ordinary, unpacked parameters (oracle/deformation_torch.py).
+    defor_depth 1 (fused kernels) and 2, 3 (csrc/deform_deep.hip)."""
+    _need_gpu()
+    import io
+    from oracle import deformation_ref as R
+    from oracle import deformation_torch as T
+    from scene.deformation import deform_network
+    a = R.Args(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000)
+    torch.manual_seed(31)
+    net = deform_network(D=D, W=128 if D == 1 else 64, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
+    with torch.no_grad():
+        net.weight.mul_(100.0)
+    ref_sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda()
+    g = torch.Generator().manual_seed(32)
+    P = 3001
+    mk = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    base = [mk(P, 3), mk(P, 3, sc=0.3) - 4, mk(P, 4), mk(P, 1), mk(P, 16, 3, sc=0.5)]
+    emb = mk(P, 32, sc=0.1)
+    ws = [mk(*t.shape) for t in base]
+    opt_g = torch.optim.Adam(net.parameters(), lr=1e-3)   # (stale packed parameters would show in the next steps' gradients)
+    opt_r = torch.optim.Adam(list(ref_sd.values()), lr=1e-3)
+    names = [n for n, _ in net.named_parameters()]
+    for step in range(3):
+        t = 0.2 + 0.3 * step
+        outs = net(*[b.cuda() for b in base[:4]], t, None, _PC(emb.cuda()), None, base[4].cuda(), iter=20000, num_down_emb_c=30, num_down_emb_f=30)
+        sum((o * w.cuda()).sum() for o, w in zip(outs[:5], ws)).backward()
+        fin, _ = T.forward(ref_sd, a, D, 150, *base, emb, t, None, 20000, 30, 30)
+        sum((o.reshape(w.shape) * w).sum() for o, w in zip(fin, ws)).backward()
+        for n in names:
+            gr, gg = ref_sd[n].grad, dict(net.named_parameters())[n].grad
+            if gr is None or float(gr.abs().max()) == 0:
+                continue
+            assert rel(gg.cpu().numpy(), gr.numpy()) <= TOL, (step, n)
+        opt_g.step(); opt_r.step()
+        opt_g.zero_grad(set_to_none=False); opt_r.zero_grad(set_to_none=False)
+        for n, p in net.named_parameters():
+            assert p.dtype == torch.float32 and float(p.grad.abs().max()) == 0.0
+    # Adam's first steps are +-lr whatever the gradient's size, so an element whose gradient is rounding noise around zero may
+    # step the other way: all elements within 3 steps' reach, all but a sliver equal to 1e-5
+    for n, p in net.named_parameters():
+        diff = (p.detach().cpu() - ref_sd[n].detach()).abs()
+        assert float(diff.max()) <= 3 * 2e-3 + 1e-6, n
+        assert float((diff > 1e-5).float().mean()) <= 0.02, (n, float((diff > 1e-5).float().mean()))
+    buf = io.BytesIO()
+    torch.save(net.state_dict(), buf)
+    buf.seek(0)
+    net2 = deform_network(D=D, W=128 if D == 1 else 64, min_embeddings=30, max_embeddings=150, num_frames=300, args=a)
+    net2.load_state_dict(torch.load(buf, weights_only=True))
+    net2 = net2.cuda()
+    with torch.no_grad():
+        o1 = net(*[b.cuda() for b in base[:4]], 0.5, None, _PC(emb.cuda()), None, base[4].cuda(), iter=20000)
+        o2 = net2(*[b.cuda() for b in base[:4]], 0.5, None, _PC(emb.cuda()), None, base[4].cuda(), iter=20000)
+    for x, y in zip(o1[:5], o2[:5]):
+        assert torch.equal(x, y)
+
+
+def test_non_fp32_parameters_are_refused():
+    _need_gpu()
+    from oracle import deformation_ref as R
+    from scene.deformation import deform_network
+    a = R.Args(no_do=False)
+    net = deform_network(D=1, W=64, min_embeddings=30, max_embeddings=150, num_frames=300, args=a).cuda().half()
+    with pytest.raises(TypeError, match="fp32"):
+        net(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 4).cuda(), torch.zeros(4, 1).cuda(),
+            0.5, None, _PC(torch.zeros(4, 32).cuda()), None, torch.zeros(4, 16, 3).cuda(), iter=10)

@@ -88,6 +88,64 @@ def test_two_ranks_take_identical_densify_decisions(tmp_path):
     assert new["xyz"].shape[0] == a["n_new"] == ns["P"] + a["counts"][0] + a["counts"][1]   # +clones, +2 per split, -split
 
 
+BATCH_WORKER = COMMON + r'''
+import os, sys, json
+sys.path.insert(0, os.path.join(%(root)r, "e-d3dgs_amd"))
+from ed3dgs_amd import dist as D
+from ed3dgs_amd import densify_stats as DS
+rank, world, local = D.init(backend="gloo")
+st = DS.DensificationStats(P, "cpu")
+for step in range(VIEWS // world):                 # every step: the ranks render DIFFERENT views, one batch of `world`
+    st.add_batched_step(*view(step * world + rank))
+try:
+    st.all_reduce_(); guard = False
+except RuntimeError:
+    guard = True
+print(json.dumps(dict(rank=rank, stats=DS.tensor_hash(st.xyz_gradient_accum, st.abs_gradient_accum, st.denom, st.max_radii2D),
+                      denom=float(st.denom.sum()), accum=float(st.xyz_gradient_accum.double().sum()), guard=guard)))
+D.destroy()
+'''
+
+
+def test_batched_step_matches_the_reference_batch_semantics(tmp_path):
+    """ADVICE r2: N ranks x one optimizer step = the reference's batch_size N (train.py:166-190, 346-348, 404-407: raw gradients
+    summed over the batch's views, visibility OR-ed, radii maxed, ONE add_densification_stats per step)."""
+    script = tmp_path / "bworker.py"
+    script.write_text(BATCH_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    res = []
+    for p in procs:
+        o, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-3000:]
+        res.append(json.loads(o.strip().splitlines()[-1]))
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["stats"] == b["stats"] and a["guard"] and b["guard"]
+    # the reference's own statements for batch_size = 2, restated: per step sum the views' grads, any() the filters, max the radii
+    ns = {}
+    exec(COMMON, ns)
+    P = ns["P"]
+    accum, denom, maxr = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+    per_view = torch.zeros(P, 1)
+    for step in range(ns["VIEWS"] // 2):
+        views = [ns["view"](2 * step + r) for r in range(2)]
+        g = torch.zeros_like(views[0][0])
+        for v in views:
+            g = g + v[0]                                                   # train.py:346-348
+        vis = torch.stack([v[1] for v in views]).any(dim=0)                  # train.py:190
+        rad = torch.stack([v[2] for v in views]).max(dim=0).values.float()   # train.py:189
+        maxr[vis] = torch.max(maxr[vis], rad[vis])                           # train.py:406
+        accum[vis] += torch.norm(g[vis, :2], dim=-1, keepdim=True)           # scene/gaussian_model.py:517
+        denom[vis] += 1                                                      # :518
+        for v in views:
+            per_view[v[1]] += torch.norm(v[0][v[1], :2], dim=-1, keepdim=True)
+    from ed3dgs_amd import densify_stats as DS
+    assert float(denom.sum()) == a["denom"]
+    assert abs(float(accum.double().sum()) - a["accum"]) <= 1e-6 * a["accum"]
+    assert float(per_view.sum()) > 1.1 * a["accum"]          # and it is NOT the per-view accumulation (add() + all_reduce_())
+
+
 def test_decisions_follow_the_reference_formulas():
     from ed3dgs_amd import densify_stats as DS
     st = DS.DensificationStats(4, "cpu")

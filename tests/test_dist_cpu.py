@@ -90,6 +90,67 @@ def test_two_rank_gradient_allreduce(tmp_path):
         assert r["out"][:4] == [1.5, 3.0, 1.5, 6.0] and all(r["out"][4:]) and r["frozen"]
 
 
+HOOK_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.path.join(%(root)r, "e-d3dgs_amd"))
+import torch
+from ed3dgs_amd import dist as D
+rank, world, local = D.init(backend="gloo")
+ps = [torch.nn.Parameter(torch.full((n,), 0.5)) for n in (5, 70000, 3, 1 << 16)]
+red = D.BucketedGradReducer(ps, bucket_bytes=200_000, average=True)
+outs = []
+for it in range(2):                       # two steps: the reducer re-arms itself
+    for p in ps:
+        p.grad = None
+    # parameter 2 takes no part in rank 1's graph; parameter 0's gradient lands LAST (it is used first)
+    x = (ps[0] * (rank + 1)).sum()
+    y = (ps[1] * (2 * (rank + 1))).sum() + (ps[3] * (4 * (rank + 1))).sum()
+    if rank == 0:
+        y = y + (ps[2] * 3.0).sum()
+    (x + y).backward()
+    early = red.issued_in_backward
+    red.finish()
+    outs.append([float(p.grad[0]) for p in ps] + [all(float(p.grad.min()) == float(p.grad.max()) for p in ps)])
+print(json.dumps(dict(rank=rank, outs=outs, buckets=len(red.buckets), early=early)))
+D.destroy()
+'''
+
+
+def test_two_rank_hooked_gradient_reducer(tmp_path):
+    """BucketedGradReducer: buckets issued from autograd hooks as their last gradient lands; same means as the after-the-fact
+    all-reduce, a missing gradient counts as zeros, and a second step works."""
+    script = tmp_path / "hworker.py"
+    script.write_text(HOOK_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    import json
+    res = []
+    for p in procs:
+        o, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        res.append(json.loads(o.strip().splitlines()[-1]))
+    for r in res:
+        assert r["buckets"] >= 3
+        for out in r["outs"]:
+            # mean over ranks: p0 (1 + 2) / 2, p1 (2 + 4) / 2, p2 (3 + 0) / 2, p3 (4 + 8) / 2
+            assert out[:4] == [1.5, 3.0, 1.5, 6.0] and out[4]
+
+
+def test_strided_visit_covers_all_cameras():
+    sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
+    from ed3dgs_amd import dist as D
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            mine = D.shard_items(400, rank, world)
+            seq = [D.strided_item(mine, k) for k in range(20)]
+            assert len(set(seq)) == 20                                           # no item twice in a 20-step run
+            assert {D.item_of(i, 8, 50)[0] for i in seq} == set(range(8)), (world, rank)   # every camera
+            assert sorted(D.strided_item(mine, k) for k in range(len(mine))) == mine  # a permutation of the shard
+
+
 def test_item_mapping_is_bijective():
     sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
     from ed3dgs_amd import dist as D

@@ -330,7 +330,19 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, missing
     assert set(_lib.EXPORTS) >= declared - {"ed3dgs_deform_cfg", "ed3dgs_state_view"}
-    assert L.ed3dgs_abi_version() == 3
+    assert L.ed3dgs_abi_version() == 4
+    # process-wide switches: read from the environment once at load, then only ed3dgs_set_option (no GPU needed)
+    assert _lib.get_option("ED3DGS_BIN_RADIX") == 0 and _lib.set_option("BIN_RADIX", 1) == 0 and _lib.get_option("BIN_RADIX") == 1
+    assert L.ed3dgs_binning_path(1000, 1920, 1080) == 0
+    _lib.set_option("BIN_RADIX", 0)
+    assert L.ed3dgs_binning_path(1000, 1920, 1080) == 2 and L.ed3dgs_binning_path(1000, 3840, 2160) == 2   # 4K: 510 super-tiles
+    assert L.ed3dgs_binning_path(1000, 4112, 400) == 1 and L.ed3dgs_binning_path(1000, 4112, 960) == 0
+    assert L.ed3dgs_set_option(b"NO_SUCH_SWITCH", 1) < 0
+    # defor_depth > 1: the extra trunk layers grow the packed block by (D - 1) (W * W + W) floats, at its end
+    mk = lambda D: _lib.DeformCfg(P=10, W=64, D=D, E=32, TD=256, n_sh=16, max_embeddings=150, num_offsets=30)
+    import ctypes as C
+    n1, n3 = L.ed3dgs_deform_param_count(C.byref(mk(1))), L.ed3dgs_deform_param_count(C.byref(mk(3)))
+    assert n3 - n1 == 2 * (64 * 64 + 64) and L.ed3dgs_deform_param_count(C.byref(mk(0))) == n1
     assert L.ed3dgs_backward_workspace_bytes(1000, 0) >= 1000 * 64
 
 

@@ -59,6 +59,7 @@ CASES = [
     ("default_w64_it500", 64, 1, 30, 150, 40, 500, 3, 0.81, 30, 30, dict()),
     ("d0_w32_it7000", 32, 0, 5, 25, 33, 7000, None, 0.05, 5, 5, dict(no_dr=True, c2f_temporal_iter=10000, deform_from_iter=5000)),
     ("d2_w32_noanneal", 32, 2, 5, 25, 20, 100, 1, 0.5, 7, 9, dict(use_anneal=False, no_do=False, no_ds=True)),
+    ("d3_w64_it2500", 64, 3, 5, 25, 37, 2500, 3, 0.4, 6, 8, dict(no_do=False, deform_from_iter=2000)),
     ("w32_nocoarse", 32, 1, 5, 25, 17, 3000, None, 0.999, 5, 5, dict(no_coarse_deform=True, no_dc=True)),
     ("w32_nofine_noc2f", 32, 1, 5, 25, 17, 3000, 2, 0.25, 5, 5, dict(no_fine_deform=True, no_c2f_temporal_embedding=True, no_do=False)),
     ("w32_reflect_time", 32, 1, 5, 25, 9, 12000, 0, 1.2, 5, 5, dict(no_do=False, temporal_embedding_dim=64)),
@@ -123,6 +124,9 @@ def run_case(mod, name, W, D, mn, mx, P, it, cam_no, time, nde_c, nde_f, over):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     mod = load_reference()
+    only = set(sys.argv[1:])   # optional: names of the cases to (re)generate; default all
     for c in CASES:
+        if only and c[0] not in only:
+            continue
         p = run_case(mod, *c)
         print(p, os.path.getsize(p) // 1024, "KiB")
