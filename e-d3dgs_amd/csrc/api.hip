@@ -61,6 +61,11 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     obtain(chunk, g.scan_space, g.scan_size, 128);
     obtain(chunk, g.point_offsets, P, 128);
     obtain(chunk, g.block_tiles, (P + 255) / 256 + 1, 128);
+    obtain(chunk, g.block_kminmax, 2 * ((P + 255) / 256 + 1), 128);
+    obtain(chunk, g.sort_a, 2 * P, 128);
+    obtain(chunk, g.sort_b, 2 * P, 128);
+    obtain(chunk, g.sort_counts, depth_sort_count_words((int)P), 128);
+    obtain(chunk, g.sort_params, 32, 128);
     obtain(chunk, g.depth_keys, P, 128);
     obtain(chunk, g.depth_keys_sorted, P, 128);
     obtain(chunk, g.ids, P, 128);
@@ -187,7 +192,10 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!rb.ev && !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipMemcpyAsync(rb.host, geom.block_tiles, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
-    if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
+    // binning level 1: the Gaussians by depth (hand-written three-pass radix sort; ED3DGS_SORT_LIBRARY=1: rocPRIM's)
+    if (opt(OPT_SORT_LIBRARY) || P > (1 << 20)) {   // (beyond 2^20 keys its per-block column sums outgrow the library's merge passes)
+        if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
+    } else if (!launch_depth_sort(geom, P, s)) return ED3DGS_ERR_HIP;
     // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5
     const bool transpose = !opt(OPT_BIN_RADIX) && bin_transpose_bytes(P, width, height, 0) > 0;
     if (!transpose) {

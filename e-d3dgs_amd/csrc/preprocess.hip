@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
     uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition,
-    uint32_t *__restrict__ block_tiles)
+    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax)
 {
     const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = idx_raw < P;
@@ -278,13 +278,23 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         ids[idx] = (uint32_t)idx;
     }
     // the block's instance count (the host adds the blocks up: num_rendered, CR/rasterizer_impl.cu:355-359 without the scan)
-    __shared__ uint32_t wave_tiles[4];
-    uint32_t t = out_tiles;
+    // and the smallest / largest depth key of its visible Gaussians (the depth sort's digits cover only the bits in which the
+    // frame's keys differ: binning.hip)
+    __shared__ uint32_t wave_tiles[4], wave_kmin[4], wave_kmax[4];
+    uint32_t t = out_tiles, kmn = out_key, kmx = out_key == 0xFFFFFFFFu ? 0u : out_key;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if ((threadIdx.x & 63) == 0) wave_tiles[threadIdx.x >> 6] = t;
+    for (int o = 32; o > 0; o >>= 1) {
+        t += __shfl_xor(t, o);
+        kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, o));
+        kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o));
+    }
+    if ((threadIdx.x & 63) == 0) { wave_tiles[threadIdx.x >> 6] = t; wave_kmin[threadIdx.x >> 6] = kmn; wave_kmax[threadIdx.x >> 6] = kmx; }
     __syncthreads();
-    if (threadIdx.x == 0) block_tiles[blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+    if (threadIdx.x == 0) {
+        block_tiles[blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+        block_kminmax[2 * blockIdx.x] = min(min(wave_kmin[0], wave_kmin[1]), min(wave_kmin[2], wave_kmin[3]));
+        block_kminmax[2 * blockIdx.x + 1] = max(max(wave_kmax[0], wave_kmax[1]), max(wave_kmax[2], wave_kmax[3]));
+    }
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means,
@@ -971,13 +981,13 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition,
-                           g.block_tiles);
+                           g.block_tiles, g.block_kminmax);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, (float *)nullptr,
-                           (uint8_t *)nullptr, g.block_tiles);
+                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax);
 }
 
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s)

@@ -11,9 +11,65 @@ namespace ed3 {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Per-(lane, Gaussian) setup of the conic quadratic, shared by forward and backward so that both directions take
-// bit-identical skip decisions (contraction is pinned: explicit fmaf only).
+// Per-(lane, Gaussian) evaluation of alpha, shared by forward and backward so that both directions take bit-identical skip
+// decisions (contraction is pinned).  Two forms:
+//
+// ED3_EXACT_ALPHA = 1 (default).  The blend decisions (alpha >= 1/255, T (1 - alpha) < 1e-4, T > 0.5) are discontinuities of the
+// output, and an fp32 evaluation of the conic quadratic is ill-conditioned for elongated Gaussians: two correct evaluations in
+// different operation orders differ by up to 1e-5 relative in alpha (measured: tools/alpha_discrepancy.py), so wherever a
+// decision sits that close to its threshold two implementations disagree by a whole 1/255-sized term.  This form therefore
+// evaluates `power` in EXACTLY the reference's operation order (CR/forward.cu:682:
+//     power = -0.5f * (con_o.x * d.x * d.x + con_o.z * d.y * d.y) - con_o.y * d.x * d.y
+// every product and sum rounded once, left to right; the factor -0.5 is exact, so the last two operations are one fused
+// multiply-subtract with the same single rounding) and exp(power) as exp2 of a two-word product: hi = fl(power * log2e),
+// lo = the exact remainder of that product plus power * (log2e - fl(log2e)), exp(power) = 2^hi (1 + lo ln 2) -- within
+// 2 ulp of a correctly rounded expf for every power the blend loop sees, which is what the oracle's libm delivers.  alpha then
+// agrees with the oracle's to 2.4e-7, decisions are taken identically unless they sit within 1e-6 of their thresholds (the
+// parity tests' exclusion margin, tests/test_raster_parity_gpu.py), and T, a product of identical operations on those alphas,
+// follows.  Cost: 6 + 5 vector operations per pixel and Gaussian instead of 2.
+//
+// ED3_EXACT_ALPHA = 0.  The round-1 form: power * log2(e) = dx (a dx + b dy) + c dy^2 with log2(e) folded into the coefficients
+// (2 FMA per pixel, the row terms shared by a lane's pixels) and a bare v_exp_f32.  Same quadratic, another rounding sequence:
+// needs an exclusion margin of 2e-5.
+#ifndef ED3_EXACT_ALPHA
+#define ED3_EXACT_ALPHA 1
+#endif
+#if ED3_EXACT_ALPHA
+struct ConicRow {
+    float cx, cy, t2, dy;   // t2 = (cz * dy) * dy: the row term of the lane
+};
+__device__ __forceinline__ ConicRow conic_row(float cx, float cy, float cz, float dy)
+{
+#pragma clang fp contract(off)
+    ConicRow r;
+    r.cx = cx; r.cy = cy; r.dy = dy;
+    r.t2 = (cz * dy) * dy;
+    return r;
+}
+// returns power (natural-log domain), rounded as the reference rounds it
+__device__ __forceinline__ float conic_power2(const ConicRow &r, float dx)
+{
+#pragma clang fp contract(off)
+    const float t1 = (r.cx * dx) * dx;
+    const float s = t1 + r.t2;
+    const float t3 = (r.cy * dx) * r.dy;
+    return __builtin_fmaf(-0.5f, s, -t3);   // -0.5 s is exact: one rounding, as in (-0.5f * s) - t3
+}
+// G = exp(power) to ~1.5 ulp: 2^hi (1 + lo ln 2), hi + lo = power * log2(e) to 2^-48
+__device__ __forceinline__ float gauss_G(float power)
+{
+    constexpr float L_HI = 1.4426950408889634f;                                    // fl(log2 e)
+    constexpr float L_LO = (float)(1.4426950408889634073599 - (double)L_HI);       // log2 e - fl(log2 e)
+    constexpr float LN2 = 0.6931471805599453f;
+    const float hi = power * L_HI;
+    float lo = __builtin_fmaf(power, L_HI, -hi);
+    lo = __builtin_fmaf(power, L_LO, lo);
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(e, lo * LN2, e);
+}
+#else
 //   power*log2(e) = dx*(a*dx + b*dy) + c*dy*dy   with a = -0.5*cx*log2e, b = -cy*log2e, c = -0.5*cz*log2e
 // (same quadratic as CR/forward.cu:682, evaluated in Horner form with the row term shared by the lane's 4 pixels).
 struct ConicRow {
@@ -35,12 +91,52 @@ __device__ __forceinline__ float conic_power2(const ConicRow &r, float dx)
 {
     return __builtin_fmaf(dx, __builtin_fmaf(r.a, dx, r.bdy), r.cdy2);
 }
-// G = exp(power), alpha = min(0.99, w*G)  (CR/forward.cu:692)
 __device__ __forceinline__ float gauss_G(float power2) { return __builtin_amdgcn_exp2f(power2); }
+#endif
+// alpha = min(0.99, w*G)  (CR/forward.cu:692)
 __device__ __forceinline__ float gauss_alpha(float w, float G)
 {
 #pragma clang fp contract(off)
     return fminf(0.99f, w * G);
+}
+
+// The same three steps for a PAIR of the lane's pixels, written on f32x2 so that they issue as v_pk_mul / v_pk_add / v_pk_fma_f32
+// (full rate: two results per issue slot; only v_exp_f32 and the min stay scalar).  Component for component the operations and
+// their order are those of conic_power2 / gauss_G / gauss_alpha above -- IEEE per component, so the results are bit-identical
+// to the scalar forms (the forward and the backward both use this one).
+struct AlphaPair {
+    f32x2 power, G, alpha;
+};
+__device__ __forceinline__ AlphaPair alpha_pair(const ConicRow &r, float w, f32x2 dx)
+{
+#pragma clang fp contract(off)
+    AlphaPair o;
+#if ED3_EXACT_ALPHA
+    constexpr float L_HI = 1.4426950408889634f;
+    constexpr float L_LO = (float)(1.4426950408889634073599 - (double)L_HI);
+    constexpr float LN2 = 0.6931471805599453f;
+    // explicit splats of values the optimiser cannot trace back to the record's float4 (it otherwise gathers them into a
+    // 4-vector and extracts the register pairs of the packed operands THROUGH SCRATCH MEMORY, inside the blend loop)
+    float cx = r.cx, cy = r.cy, t2 = r.t2, dy = r.dy;
+    asm volatile("" : "+v"(cx), "+v"(cy), "+v"(t2), "+v"(dy));
+    const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, t22 = {t2, t2}, dy2 = {dy, dy};
+    const f32x2 t1 = (cx2 * dx) * dx;
+    const f32x2 s = t1 + t22;
+    const f32x2 t3 = (cy2 * dx) * dy2;
+    o.power = __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, s, -t3);
+    const f32x2 hi = o.power * L_HI;
+    f32x2 lo = __builtin_elementwise_fma(o.power, f32x2{L_HI, L_HI}, -hi);
+    lo = __builtin_elementwise_fma(o.power, f32x2{L_LO, L_LO}, lo);
+    const f32x2 e = {__builtin_amdgcn_exp2f(hi.x), __builtin_amdgcn_exp2f(hi.y)};
+    o.G = __builtin_elementwise_fma(e, lo * LN2, e);
+#else
+    const f32x2 inner = __builtin_elementwise_fma(f32x2{r.a, r.a}, dx, f32x2{r.bdy, r.bdy});
+    o.power = __builtin_elementwise_fma(dx, inner, f32x2{r.cdy2, r.cdy2});
+    o.G = f32x2{__builtin_amdgcn_exp2f(o.power.x), __builtin_amdgcn_exp2f(o.power.y)};
+#endif
+    const f32x2 araw = w * o.G;
+    o.alpha = f32x2{fminf(0.99f, araw.x), fminf(0.99f, araw.y)};
+    return o;
 }
 
 // Tile-level reject, evaluated by ONE lane per list entry while the chunk is staged: can this Gaussian reach

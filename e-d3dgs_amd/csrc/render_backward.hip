@@ -17,8 +17,6 @@
 
 namespace ed3 {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
@@ -267,16 +265,15 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             bool med[4];
             bool any_valid = false;
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                dx[p] = r0.x - fpx[p];
-                const float pw2 = conic_power2(cr, dx[p]);
-                const float Gp = gauss_G(pw2);
-                const float ap = gauss_alpha(r1.y, Gp);
-                const bool vd = (k < last[p]) && !(pw2 > 0.0f) && !(ap < ALPHA_MIN);
-                any_valid |= vd;
-                alpha[p] = vd ? ap : 0.f;
-                G[p] = vd ? Gp : 0.f;
-                med[p] = vd && (k + 1u == maxc[p]);
+            for (int q = 0; q < 2; q++) {   // pixel pairs: the same packed evaluation as the forward's (raster_common.h)
+                dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
+                const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
+                const bool v0 = (k < last[2 * q]) && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
+                const bool v1 = (k < last[2 * q + 1]) && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
+                any_valid |= v0 | v1;
+                alpha[2 * q] = v0 ? ap.alpha.x : 0.f; alpha[2 * q + 1] = v1 ? ap.alpha.y : 0.f;
+                G[2 * q] = v0 ? ap.G.x : 0.f; G[2 * q + 1] = v1 ? ap.G.y : 0.f;
+                med[2 * q] = v0 && (k + 1u == maxc[2 * q]); med[2 * q + 1] = v1 && (k + 1u == maxc[2 * q + 1]);
             }
             if (!__any(any_valid)) continue;
             if (counters) {   // per lane; summed over the wave once, at the end of the tile

@@ -94,13 +94,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             bool valid[4];
             bool any_valid = false;
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                dx[p] = r0.x - fpx[p];
-                const float pw2 = conic_power2(cr, dx[p]);
-                const float G = gauss_G(pw2);
-                alpha[p] = gauss_alpha(r1.y, G);
-                valid[p] = !done[p] && !(pw2 > 0.0f) && !(alpha[p] < ALPHA_MIN);
-                any_valid |= valid[p];
+            for (int q = 0; q < 2; q++) {   // pixel pairs: the alpha evaluation issues as packed fp32 (raster_common.h)
+                dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
+                const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
+                alpha[2 * q] = ap.alpha.x; alpha[2 * q + 1] = ap.alpha.y;
+                valid[2 * q] = !done[2 * q] && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
+                valid[2 * q + 1] = !done[2 * q + 1] && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
+                any_valid |= valid[2 * q] | valid[2 * q + 1];
             }
             if (!__any(any_valid)) continue;
             if (counters) { n_iter++; n_pair += (unsigned)valid[0] + valid[1] + valid[2] + valid[3]; }

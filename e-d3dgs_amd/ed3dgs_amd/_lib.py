@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc"))
-LIB_PATH = os.path.join(_CSRC, "libed3dgs_hip.so")
+# ED3DGS_LIB_PATH: another build of the same library (A/B experiments of compile-time options: tools/ab_build.sh)
+LIB_PATH = os.environ.get("ED3DGS_LIB_PATH") or os.path.join(_CSRC, "libed3dgs_hip.so")
 _lib = None
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

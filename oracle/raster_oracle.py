@@ -54,6 +54,12 @@ def set_eig_epsilon(e):
     lib().ed3ref_set_eig_epsilon(C.c_double(e))
 
 
+def set_margin_weights(alpha=1.0, termination=1.0, median=1.0):
+    """Per-decision weights of the forward's per-pixel margin (ed3ref_set_margin_weights in raster_ref.c): the margin is the
+    minimum over the pixel's decisions of (relative distance to the threshold) / weight; 0 leaves a decision kind out."""
+    lib().ed3ref_set_margin_weights(C.c_double(alpha), C.c_double(termination), C.c_double(median))
+
+
 def get_eig_epsilon():
     return float(lib().ed3ref_get_eig_epsilon())
 

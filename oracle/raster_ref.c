@@ -167,6 +167,13 @@ static int feq(float x, float y, float eps) { return fabsf(x - y) <= eps; }     
  * from everything else (tests/test_oracle_pins_cpu.py); every parity comparison runs at the reference's value. */
 static float g_eig_epsilon = 0.0000001f;
 void ed3ref_set_eig_epsilon(double e) { g_eig_epsilon = (float)e; }
+/* Which decisions feed the per-pixel margin of ed3ref_render_forward, each divided by its own weight before the minimum is
+ * taken: [0] the alpha threshold (and power > 0), [1] termination T(1 - alpha) < 1e-4, [2] the median test T > 0.5.
+ * Weight 1 for all = the plain smallest relative distance.  A test that tolerates a larger discrepancy in T than in alpha
+ * (a long product of factors) passes weights < 1 for [1] and [2]; weight 0 leaves a decision kind out (diagnostics). */
+static float g_margin_weight[3] = {1.0f, 1.0f, 1.0f};
+void ed3ref_set_margin_weights(double a, double t, double m) { g_margin_weight[0] = (float)a; g_margin_weight[1] = (float)t; g_margin_weight[2] = (float)m; }
+static inline float margin_term(float d, int kind) { return g_margin_weight[kind] > 0.0f ? d / g_margin_weight[kind] : INFINITY; }
 double ed3ref_get_eig_epsilon(void) { return (double)g_eig_epsilon; }
 static float transfer_sign(float v, float s) { return (s >= 0) ? fabsf(v) : -fabsf(v); } /* :195-198 */
 static float pythag(float a, float b)                                                  /* :201-214 */
@@ -605,20 +612,20 @@ void ed3ref_render_forward(int W, int H, const uint32_t *ranges, const uint32_t 
                 float dx = means2D[2 * g] - pixfx, dy = means2D[2 * g + 1] - pixfy;
                 const float *co = conic_opacity + 4 * g;
                 float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                if (margin && fabsf(power) < 1e-4f) mg = fminf(mg, fabsf(power));
+                if (margin && fabsf(power) < 1e-4f) mg = fminf(mg, margin_term(fabsf(power), 0));
                 if (power > 0.0f) continue;
                 float araw = co[3] * expf(power);
                 float alpha = minf(0.99f, araw);
-                if (margin) mg = fminf(mg, fabsf(araw - 1.0f / 255.0f) * 255.0f);
+                if (margin) mg = fminf(mg, margin_term(fabsf(araw - 1.0f / 255.0f) * 255.0f, 0));
                 if (alpha < 1.0f / 255.0f) continue;
                 float test_T = T * (1 - alpha);
-                if (margin) mg = fminf(mg, fabsf(test_T - 0.0001f) / 0.0001f);
+                if (margin) mg = fminf(mg, margin_term(fabsf(test_T - 0.0001f) / 0.0001f, 1));
                 if (test_T < 0.0001f) break; /* done=true ends the pixel (:696-700) */
                 const float aT = alpha * T;
                 for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * g + ch] * aT;
                 tongue += is_tongue[g] * aT;
                 int before_median = T > 0.5;
-                if (margin && GEO) mg = fminf(mg, fabsf(T - 0.5f) / 0.5f);
+                if (margin && GEO) mg = fminf(mg, margin_term(fabsf(T - 0.5f) / 0.5f, 2));
                 if (COORD) {
                     const float *cp = camera_planes + 6 * g;
                     float coord[3] = {view_points[3 * g] + cp[0] * dx + cp[1] * dy,

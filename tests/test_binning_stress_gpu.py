@@ -63,6 +63,13 @@ CASES = {
     "one-tile": lambda: (util.scene_inputs(500, 16, 16, scene_seed=13, cam_seed=14), 2),
     "one-row": lambda: (util.scene_inputs(1, 400, 400, scene_seed=15, cam_seed=16), 2),
     "1025-rows": lambda: (util.scene_inputs(1025, 640, 480, scene_seed=17, cam_seed=18), 2),
+    # every Gaussian at the same point: ONE depth key, every tie resolved by id (the depth sort's digits are 1 bit wide)
+    "identical-depths": lambda: (dict(util.scene_inputs(3000, 640, 480, scene_seed=29, cam_seed=30),
+                                      means3D=util.scene_inputs(3000, 640, 480, scene_seed=29, cam_seed=30)["means3D"] * 0.0), 2),
+    # depth keys over many binades (the depth sort's widest digits) and more than one sort tile of 4096 keys
+    "deep-range-9k": lambda: (dict(util.scene_inputs(9000, 800, 608, scene_seed=31, cam_seed=32),
+                                   means3D=util.scene_inputs(9000, 800, 608, scene_seed=31, cam_seed=32)["means3D"]
+                                   * torch.logspace(-2.5, 1.0, 9000)[:, None]), 2),
 }
 
 
@@ -71,6 +78,13 @@ def test_lists_bit_exact(case):
     _need_gpu()
     fw = _lists_equal(*CASES[case]())
     print(case, "instances", fw["num_rendered"], "visible", int((fw["radii"] > 0).sum()))
+
+
+def test_library_depth_sort_agrees(libopt):
+    """ED3DGS_SORT_LIBRARY=1: rocPRIM's sort in place of the hand-written three-pass radix sort of binning level 1."""
+    _need_gpu()
+    libopt("SORT_LIBRARY", 1)
+    _lists_equal(_giants(util.scene_inputs(20000, 1100, 1604, scene_seed=19, cam_seed=20), 10, 30.0), 2)
 
 
 @pytest.mark.parametrize("switch,path", [("BIN_ONE_LEVEL", 1), ("BIN_RADIX", 0)])

@@ -23,8 +23,16 @@ def scene_inputs(P, W, H, scene_seed=0, cam_seed=1, cam_index=0, n_cams=1, kerne
         tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=kernel_size, scale_modifier=1.0, sh_degree=3)
 
 
+# Exclusion margin of the parity tests (relative distance of a blend decision to its threshold in the ORACLE's forward):
+# MARGIN on alpha >= 1/255 (and power > 0), MARGIN x 5 on T (1 - alpha) < 1e-4 and on T > 0.5 -- T is a product of up to
+# hundreds of (1 - alpha) factors, so a 2.4e-7 disagreement in single alphas is a larger one in T.
+MARGIN = 1e-6
+MARGIN_WEIGHTS = (1.0, 5.0, 5.0)
+
+
 def oracle_forward(inp, variant, with_margin=True, colors_precomp=None, cov3D_precomp=None):
     from oracle import raster_oracle as O
+    O.set_margin_weights(*MARGIN_WEIGHTS)
     rc, rd = VARIANTS[variant]
     n = lambda t: None if t is None else t.detach().cpu().numpy()
     use_cov = cov3D_precomp is not None
