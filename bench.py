@@ -31,7 +31,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-operand MFMA peak (MI355X_MICROARCH.md, matrix-core table)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
-MODE_OPTS = ("DEFORM_FP32_MFMA", "DEFORM_BF16X3", "DEFORM_NO_PIPE")   # library switches (ed3dgs_set_option) that select another MLP multiply mode
+MODE_OPTS = ("DEFORM_FP32_MFMA", "DEFORM_BF16X3")   # library switches (ed3dgs_set_option) that select another MLP multiply mode
 WORKLOADS = {
     "C3": dict(P=200_000, W=1920, H=1080, cams=8, frames=50, deform=True,
                name="C3: 200k Gaussians, 8 cams x 50 timesteps, 1080p, deform MLP W=128 D=1, depth+normal (FTT)"),
@@ -401,10 +401,11 @@ def main():
     k6_count_ms = cnt_ms[0] / max(cnt_n[0], 1)
     dom = max([i for i in range(NS) if i != 4], key=lambda i: tab_avg[i])   # the dominant single KERNEL
 
-    # ---- timed: exactly K steps; events only around the dominant kernel and K7 ----
+    # ---- timed: exactly K steps; events only around the dominant kernel (every event pair is a barrier packet on the launch
+    # stream, ~6 us of gap: K7 and the others are timed in the instrumented pass above) ----
     torch.cuda.synchronize(); D.barrier()
     log("timed region")
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint((1 << dom) | 2))
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(1 << dom))
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]   # step boundaries on the launch stream
     t0 = time.perf_counter()
     marks[0].record()
@@ -462,7 +463,7 @@ def main():
         finally:
             _lib.set_option(var, 0)
 
-    mode = "fp32_mfma" if _lib.get_option("DEFORM_FP32_MFMA") or _lib.get_option("DEFORM_NO_PIPE") else \
+    mode = "fp32_mfma" if _lib.get_option("DEFORM_FP32_MFMA") else \
            "bf16x3" if _lib.get_option("DEFORM_BF16X3") else "exact_split"
     f32m = other_mode("DEFORM_FP32_MFMA",
                       "ED3DGS_DEFORM_FP32_MFMA=1: every MLP contraction on v_mfma_f32_32x32x2_f32 (the round's first kernels; "
@@ -548,7 +549,7 @@ def main():
     # SIMD issues one per cycle, 1024 SIMDs at 2.4 GHz; iterations and blended pairs are COUNTED by the kernel in the
     # instrumented pass (popcount of the valid masks), the time is that pass's launch time with the counting on
     K7_ISSUE_CYCLES_PER_ITER = 211 * 4 + 8 * 8
-    it_per_s = k7_work[0] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0   # counts are per item (deterministic); time = the timed region's launches
+    it_per_s = k7_work[0] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0   # counts are per item (deterministic); time = the instrumented pass's launches
     valu_roof = {"visited_iterations_per_launch": k7_work[0], "blended_pairs_per_launch": k7_work[1],
                  "list_entries_staged_per_launch": k7_work[2], "entries_kept_by_tile_reject_per_launch": k7_work[3],
                  "pairs_per_iteration": k7_work[1] / k7_work[0] if k7_work[0] else 0.0,
@@ -581,7 +582,8 @@ def main():
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                "traffic": pmc.get("render_backward_kernel<false,true>"), "traffic_source": traffic_source,
-               "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1],
+               "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1] or tab_n[1],
+               "time_source": "timed region" if slot_n[1] else "instrumented pass of the same steps (hipEvent pairs on the launch stream)",
                "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                "valu_roof": valu_roof,
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "

@@ -192,8 +192,10 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!rb.ev && !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipMemcpyAsync(rb.host, geom.block_tiles, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
     if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
-    // binning level 1: the Gaussians by depth (hand-written three-pass radix sort; ED3DGS_SORT_LIBRARY=1: rocPRIM's)
-    if (opt(OPT_SORT_LIBRARY) || P > (1 << 20)) {   // (beyond 2^20 keys its per-block column sums outgrow the library's merge passes)
+    // binning level 1: the Gaussians by depth.  The library's sort (rocPRIM merge sort below a million keys: 9 launches, 60-70 us
+    // at 200k) stays the default: the hand-written three-pass radix sort (binning.hip, ED3DGS_SORT_HANDWRITTEN=1) is bit-identical
+    // and takes 6 launches but 80 us -- measured in round 3
+    if (!opt(OPT_SORT_HANDWRITTEN) || P > (1 << 20)) {
         if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     } else if (!launch_depth_sort(geom, P, s)) return ED3DGS_ERR_HIP;
     // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5

@@ -77,8 +77,12 @@ bool run_sort(char *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout
 //            are found with w ballots, their rank is a popcount, the row's count goes to the wave's running counter by ONE
 //            LDS atomic whose returned value is broadcast to them (no atomic's order decides a position) -- and writes
 //            (key, id) to its place.  Waves, rows and lanes are walked in order: the pass is stable.
-// 6 launches, ~25 us at 200k keys (the library's merge sort behind hipcub::DeviceRadixSort: 9 launches, 60-70 us; its Onesweep
-// radix sort, forced: 15 launches, 155 us).  ED3DGS_SORT_LIBRARY=1 restores the library call (A/B, tests).
+// 6 launches.  MEASURED (round 3, 200k keys): count 6-7 us, scatter 18-22 us per pass, 81 us in all -- SLOWER than the library's
+// merge sort behind hipcub::DeviceRadixSort (9 launches, 60-70 us; its Onesweep radix sort, forced: 15 launches, 155 us): 49
+// tiles occupy 49 of 256 CUs, and a scatter block is five dependent phases (frame extremes, column sums, key loads, 16 ranked
+// rows, scattered stores) of one or two memory / LDS-atomic latencies each.  It therefore stays OPT-IN (ED3DGS_SORT_HANDWRITTEN=1;
+// bit-identical lists: tests/test_binning_stress_gpu.py); what would beat the library is a single launch per pass with a
+// decoupled look-back instead of count + column sums, not attempted.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int DS_TILE = 4096, DS_IPT = 16, DS_MAXBINS = 2048;
 
@@ -161,23 +165,47 @@ __global__ void __launch_bounds__(256) depth_sort_scatter_kernel(DepthSort a)
     const int bins = 1 << w, shift = a.pass * w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = tid; q < 4 * DS_MAXBINS; q += 256) (&wcnt[0][0])[q] = 0u;
-    // column sums: thread t owns digits 8 t .. 8 t + 7 (two 16-byte loads per tile row, the rows' loads independent)
+    // column sums: digits in groups of 8 (two 16-byte loads per tile row); the block's 256 threads split the tiles of a group
+    // among themselves and keep FOUR rows' loads in flight each (a thread walking all tiles of its group alone is a chain of
+    // ntiles memory latencies: 30 us per pass at 200k keys), partial sums meet in LDS
+    __shared__ uint32_t pre_s[DS_MAXBINS], all_s[DS_MAXBINS];
+    for (int q = tid; q < bins; q += 256) { pre_s[q] = 0u; all_s[q] = 0u; }
+    __syncthreads();
+    if (bins >= 8) {
+        const int ngrp = bins >> 3, parts = max(1, 256 / ngrp);
+        const int grp = tid % ngrp, part = tid / ngrp;
+        if (part < parts) {
+            uint32_t pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, aa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t0 = part; t0 < a.ntiles; t0 += 4 * parts) {
+                uint4 lo[4], hi[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = min(t0 + u * parts, a.ntiles - 1);
+                    lo[u] = *reinterpret_cast<const uint4 *>(a.counts + (size_t)t * bins + 8 * grp);
+                    hi[u] = *reinterpret_cast<const uint4 *>(a.counts + (size_t)t * bins + 8 * grp + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + u * parts;
+                    if (t >= a.ntiles) continue;
+                    const uint32_t v[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { aa[q] += v[q]; pp[q] += t < (int)blockIdx.x ? v[q] : 0u; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { atomicAdd(&all_s[8 * grp + q], aa[q]); atomicAdd(&pre_s[8 * grp + q], pp[q]); }
+        }
+    } else if (tid == 0) {
+        for (int t = 0; t < a.ntiles; t++)
+            for (int q = 0; q < bins; q++) { const uint32_t v = a.counts[(size_t)t * bins + q]; all_s[q] += v; pre_s[q] += t < (int)blockIdx.x ? v : 0u; }
+    }
+    __syncthreads();
     const int d0 = 8 * tid;
     uint32_t pre[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (d0 < bins) {
-        if (bins >= 8) {
-            for (int t = 0; t < a.ntiles; t++) {
-                const uint4 lo = *reinterpret_cast<const uint4 *>(a.counts + (size_t)t * bins + d0);
-                const uint4 hi = *reinterpret_cast<const uint4 *>(a.counts + (size_t)t * bins + d0 + 4);
-                const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                for (int q = 0; q < 8; q++) { all[q] += v[q]; pre[q] += t < (int)blockIdx.x ? v[q] : 0u; }
-            }
-        } else {
-            for (int t = 0; t < a.ntiles; t++)
-                for (int q = 0; q < bins; q++) { const uint32_t v = a.counts[(size_t)t * bins + q]; all[q] += v; pre[q] += t < (int)blockIdx.x ? v : 0u; }
-        }
-    }
+    for (int q = 0; q < 8; q++)
+        if (d0 + q < bins) { pre[q] = pre_s[d0 + q]; all[q] = all_s[d0 + q]; }
     // exclusive scan of the digit totals over the block: 8 per thread, a wave scan, the four wave sums
     uint32_t mine = 0;
 #pragma unroll

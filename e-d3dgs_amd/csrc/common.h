@@ -25,9 +25,8 @@ enum { G_R = 0, G_G, G_B, G_TS, G_RPX, G_RPY, G_NX, G_NY, G_NZ, G_MX, G_MY, G_MZ
 // (ED3DGS_<name>=<int>; any non-numeric non-empty value counts as 1), and changed afterwards only through
 // ed3dgs_set_option() -- no entry point reads the environment per call.
 #define ED3_OPTIONS(X) \
-    X(BIN_ONE_LEVEL) X(BIN_RADIX) X(BIN_TIMING) X(SORT_LIBRARY) \
-    X(DEFORM_BF16X3) X(DEFORM_DENSE_BWD) X(DEFORM_DW1_GENERIC) X(DEFORM_FP32_MFMA) X(DEFORM_FUSED_BWD) \
-    X(DEFORM_GENERIC_WGRAD) X(DEFORM_NO_PIPE) X(DEFORM_NO_TAIL) X(DEFORM_WGRAD_R1) X(FB_ABLATE) X(FWD_TIMING) \
+    X(BIN_ONE_LEVEL) X(BIN_RADIX) X(BIN_TIMING) X(SORT_HANDWRITTEN) \
+    X(DEFORM_BF16X3) X(DEFORM_DENSE_BWD) X(DEFORM_FP32_MFMA) X(DEFORM_NO_TAIL) X(FB_ABLATE) X(FWD_TIMING) \
     X(PREP_SEQ) X(STATS_BLOCKS) X(WG_ABLATE) X(WG_TIMING)
 enum Opt {
 #define X(n) OPT_##n,

@@ -30,6 +30,14 @@ namespace ed3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Piece products of the exact three-piece multiply (x = x0 + x1 + x2, w = w0 + w1 + w2, bf16 pieces): the products w_i x_j with
+// i + j <= ED3_NP3_SMAX are accumulated.  3 (default): eight products, all but w2 x2 (2^-32 of the leading one) -- every
+// multiply more exact than one fp32 rounding.  2: six products (drops w1 x2 and w2 x1, each <= 2^-24 of the product: the size
+// of an fp32 multiply's own rounding) -- a MEASURED option only (tools/ab_build.sh six -DED3_NP3_SMAX=2).
+#ifndef ED3_NP3_SMAX
+#define ED3_NP3_SMAX 3
+#endif
+
 __device__ __forceinline__ int fslot(int kk, int h) { return (kk & 3) + 8 * (kk >> 2) + 4 * h; }
 
 // fragment workspace of one stage (float offsets)
@@ -537,109 +545,6 @@ __device__ __forceinline__ void load_emb_slots(const float *__restrict__ emb, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// forward: one wave per strip of 32 Gaussians, both stages, five heads, register resident
-// ------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_forward_kernel(DeformDev d)
-{
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int nstrips = (d.P + 31) / 32;
-    const int shw = 3 * d.n_sh;
-    for (int strip = wave; strip < nstrips; strip += nwaves) {
-        const int g_raw = strip * 32 + (lane & 31);
-        const bool gvalid = g_raw < d.P;
-        const int g = gvalid ? g_raw : d.P - 1;
-        // current values (updated stage by stage)
-        float cx[3], cs[3], cr[4], co, csh[24];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { cx[i] = d.xyz[(size_t)g * 3 + i]; cs[i] = d.scales[(size_t)g * 3 + i]; }
-#pragma unroll
-        for (int i = 0; i < 4; i++) cr[i] = d.rot[(size_t)g * 4 + i];
-        co = d.opacity[g];
-#pragma unroll
-        for (int c = 0; c < 6; c++) {  // chunks: tile c>>2, q = c&3 -> features (c>>2)*32 + 8q + 4h
-            const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (feat < shw) v = load_sh4(d, g, feat, shw);
-            csh[4 * c] = v.x; csh[4 * c + 1] = v.y; csh[4 * c + 2] = v.z; csh[4 * c + 3] = v.w;
-        }
-        for (int s = 0; s < 2; s++) {
-            if (d.use_stage[s]) {
-                const float *fr = d.frag[s];
-                float a[NT][16];
-                {   // trunk: hid = hb + W1[:, TD:] emb ; a = relu(hid)
-                    f32x16 acc[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++) acc[nt] = bias_acc(fr + d.fl.HB, nt, h);
-                    for (int et = 0; et < d.ET; et++) {
-                        float eb[1][16];
-                        load_emb_slots(d.emb, d.E, g, et, h, eb[0]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; nt++)
-                            acc[nt] = gemm_tile<1>(fr + d.fl.F1 + ((size_t)nt * d.ET + et) * 1024, eb, acc[nt], lane);
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[nt][r], 0.f);
-                }
-                for (int k = 0; k < NHEAD; k++) {
-                    if (!d.enabled[k]) continue;
-                    // head hidden tile by tile: z_nt = relu(b2 + W2[nt,:] a) is consumed at once as k-tile nt of the
-                    // output GEMM, so only one 32x32 z tile is live
-                    f32x16 y[OTMAX];
-#pragma unroll
-                    for (int ot = 0; ot < OTMAX; ot++) y[ot] = bias_acc(fr + d.fl.B3 + (size_t)k * OTMAX * 32, ot, h);
-                    const int nout = d.ot[k];
-#pragma unroll 1
-                    for (int nt = 0; nt < NT; nt++) {
-                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-                        acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
-                        float z[1][16];
-#pragma unroll
-                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
-                        y[0] = gemm_tile<1>(fr + d.fl.F3 + ((((size_t)k * OTMAX + 0) * NT) + nt) * 1024, z, y[0], lane);
-                        if (nout > 1)
-                            y[1] = gemm_tile<1>(fr + d.fl.F3 + ((((size_t)k * OTMAX + 1) * NT) + nt) * 1024, z, y[1], lane);
-                    }
-                    const float hc = d.hc[k];
-                    if (k == 0) { if (h == 0) { cx[0] += y[0][0] * hc; cx[1] += y[0][1] * hc; cx[2] += y[0][2] * hc; } }
-                    else if (k == 1) { if (h == 0) { cs[0] += y[0][0] * hc; cs[1] += y[0][1] * hc; cs[2] += y[0][2] * hc; } }
-                    else if (k == 2) { if (h == 0) { cr[0] += y[0][0] * hc; cr[1] += y[0][1] * hc; cr[2] += y[0][2] * hc; cr[3] += y[0][3] * hc; } }
-                    else if (k == 3) { if (h == 0) co += y[0][0] * hc; }
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) csh[r] += y[0][r] * hc;
-#pragma unroll
-                        for (int r = 0; r < 8; r++) csh[16 + r] += y[1][r] * hc;
-                    }
-                }
-            }
-            // write: after the coarse stage -> sub_*, after the fine stage -> out_*
-            float *const *dst = (s == 0) ? d.sub : d.out;
-            if (gvalid && dst[0]) {
-                if (h == 0) {
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { dst[0][(size_t)g * 3 + i] = cx[i]; dst[1][(size_t)g * 3 + i] = cs[i]; }
-                    *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
-                    dst[3][g] = co;
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
-                    if (feat < shw)
-                        *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
-                            make_float4(csh[4 * c], csh[4 * c + 1], csh[4 * c + 2], csh[4 * c + 3]);
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // backward, input-gradient part: recompute, back-propagate through the heads and the trunk, store the matrices the
 // weight-gradient reduction needs, write dL/d embedding
 // ------------------------------------------------------------------------------------------------------------
@@ -648,140 +553,6 @@ __device__ __forceinline__ void store_tile_rows(float *__restrict__ M, int ld, i
     float4 *row = reinterpret_cast<float4 *>(M + (size_t)g * ld + nt * 32 + 4 * h);
 #pragma unroll
     for (int q = 0; q < 4; q++) row[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-
-template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_dgrad_kernel(DeformDev d)
-{
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int nstrips = (d.P + 31) / 32;
-    const int shw = 3 * d.n_sh;
-    const bool both = d.use_stage[0] && d.use_stage[1];
-    for (int strip = wave; strip < nstrips; strip += nwaves) {
-        const int g_raw = strip * 32 + (lane & 31);
-        const bool gvalid = g_raw < d.P;
-        const int g = gvalid ? g_raw : d.P - 1;
-        float eb[1][16];
-        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);  // ET == 1 in the backward (checked on the host)
-        f32x16 ge;
-#pragma unroll
-        for (int r = 0; r < 16; r++) ge[r] = 0.f;
-        for (int s = 0; s < 2; s++) {
-            if (!d.use_stage[s]) continue;
-            const float *fr = d.frag[s];
-            // gradient reaching this stage's head outputs: fine stage (or a lone stage) sees dL/d out; the coarse
-            // stage sees dL/d out + dL/d sub (out = sub + coef * delta_f)
-            const bool add_sub = (s == 0);
-            const bool add_out = (s == 1) || both || !d.use_stage[1];
-            float a[NT][16];
-            {
-                f32x16 acc[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    acc[nt] = bias_acc(fr + d.fl.HB, nt, h);
-                    acc[nt] = gemm_tile<1>(fr + d.fl.F1 + (size_t)nt * 1024, eb, acc[nt], lane);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) a[nt][r] = fmaxf(acc[nt][r], 0.f);
-                    if (gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, a[nt]);
-                }
-            }
-            f32x16 ga[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) ga[nt][r] = 0.f;
-            for (int k = 0; k < NHEAD; k++) {
-                if (!d.enabled[k]) continue;
-                // B operand of the head-output backward: gy[ot][kk] = hc * g_head[g][ot*32 + f(kk,h)]
-                const float hc = d.hc[k];
-                const int nk = d.nk[k];
-                float gy[OTMAX][16];
-#pragma unroll
-                for (int ot = 0; ot < OTMAX; ot++)
-#pragma unroll
-                    for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
-                if (k < 4) {
-                    if (h == 0) {
-                        for (int j = 0; j < nk; j++) {  // features 0..nk-1 are k-slots kk = j of half 0
-                            float v = 0.f;
-                            if (add_out && d.g[k]) v += d.g[k][(size_t)g * nk + j];
-                            if (add_sub && d.gs[k]) v += d.gs[k][(size_t)g * nk + j];
-                            gy[0][j] = v * hc;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        const int feat = (c >> 2) * 32 + 8 * (c & 3) + 4 * h;
-                        float4 v = make_float4(0, 0, 0, 0);
-                        if (feat < shw) {
-                            if (add_out && d.g[4]) { float4 t = *reinterpret_cast<const float4 *>(d.g[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                            if (add_sub && d.gs[4]) { float4 t = *reinterpret_cast<const float4 *>(d.gs[4] + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                        }
-                        const int ot = c >> 2, kk0 = 4 * (c & 3);
-                        gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
-                    }
-                }
-                // one 32-feature tile of the head hidden at a time: recompute z_nt, store relu(z_nt), form
-                // g_z_nt = (W3^T g_y)_nt masked by z_nt > 0, store it, and push it through W2^T into g_a
-#pragma unroll 1
-                for (int nt = 0; nt < NT; nt++) {
-                    float z[1][16];
-                    {
-                        f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-                        acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
-#pragma unroll
-                        for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r], 0.f);
-                    }
-                    if (gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-                    if (k < 4) {  // 3 / 3 / 4 / 1 outputs: only the first k-slots of half 0 are non-zero
-                        const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX) * 16) * 64;
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int ot = 0; ot < OTMAX; ot++) {
-                            const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX + ot) * 16) * 64;
-#pragma unroll
-                            for (int kk = 0; kk < 16; kk++)
-                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[ot][kk], acc, 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; r++) z[0][r] = z[0][r] > 0.f ? acc[r] : 0.f;
-                    if (gvalid) store_tile_rows(d.GZ[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
-#pragma unroll
-                    for (int it = 0; it < NT; it++)
-                        ga[it] = gemm_tile<1>(fr + d.fl.F2T + ((((size_t)k * NT + it) * NT) + nt) * 1024, z, ga[it], lane);
-                }
-            }
-            // g_hid = g_a masked by hid > 0 ; stored ; g_emb += W1[:, TD:]^T g_hid
-            float gh[NT][16];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) gh[nt][r] = a[nt][r] > 0.f ? ga[nt][r] : 0.f;
-                if (gvalid) store_tile_rows(d.GHID[s], d.W, g, nt, h, gh[nt]);
-            }
-            ge = gemm_tile<NT>(fr + d.fl.F1T, gh, ge, lane);
-        }
-        if (gvalid) {
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = ge[r];
-            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1250,7 +1021,7 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
         // NP = 2: the three products with i + j <= 1.  NP = 3: every product except the last piece times the last piece
         // (2^-32 of the leading one): eight products, each exact in fp32 -- the sum of piece products is then w x to
         // 2^-32, i.e. MORE exact than the single rounding of an fp32 multiply; accumulation is fp32 either way.
-        constexpr int SMAX = NP == 2 ? 1 : 3;
+        constexpr int SMAX = NP == 2 ? 1 : ED3_NP3_SMAX;
 #pragma unroll
         for (int sum = SMAX; sum >= 0; sum--)        // smallest products first
 #pragma unroll
@@ -2153,345 +1924,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef EN_K
 
 // ------------------------------------------------------------------------------------------------------------
-// fused backward (W <= 128): head-specialised blocks.
-//   P1 deform_bwd_head_kernel : block = (row group, head k, stage s), 4 waves = 4 strips of 32 Gaussians per iteration.
-//      Recomputes a = relu(hid) and z_k, forms g_z_k in registers, and accumulates dW3_k = g_y^T relu(z_k) and
-//      dW2_k = g_z_k^T a ON CHIP: the register tiles (feature on the register, Gaussian on the lane) are transposed
-//      through LDS ([row][feature], row stride 132 floats -> conflict-free b128 writes and b32 operand reads) so that
-//      the Gaussian index becomes the MFMA k index; every wave owns a 2x2 patch of dW2_k (and <= 2 tiles of dW3_k) in
-//      accumulator registers for the whole kernel and flushes once.  Only g_a_k = W2_k^T g_z_k leaves the chip
-//      (512 B per Gaussian per head instead of the 12 x 512 B the generic path stores and re-reads).
-//   P2 deform_bwd_trunk_kernel: sums the five g_a_k, masks with a > 0, accumulates dW1[:, TD:] and db1 the same way and
-//      writes dL/d embedding.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int FB_LD = 132;     // LDS row stride (floats) of the transposed tiles
-constexpr int FB_ROWS = 128;   // Gaussians per block iteration (4 waves x 32)
-
-__device__ __forceinline__ void lds_store_tile_T(float *__restrict__ base, int row, int nt, int h, const float (&v)[16])
-{
-    float4 *p = reinterpret_cast<float4 *>(base + row * FB_LD + nt * 32 + 4 * h);
-#pragma unroll
-    for (int q = 0; q < 4; q++) p[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-
-template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_bwd_head_kernel(DeformDev d, float *GA0, float *GA1, float *gp0, float *gp1, ParamLayout pl)
-{
-    extern __shared__ float fb_lds[];
-    float *A_T = fb_lds;                         // [128][132]  a^T
-    float *Z_T = fb_lds + FB_ROWS * FB_LD;       // [128][132]  relu(z)^T, then g_z^T
-    const int s = blockIdx.z, k = blockIdx.y;
-    if (!d.use_stage[s] || !d.enabled[k]) return;
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float *fr = d.frag[s];
-    float *GA = (s == 0 ? GA0 : GA1) + (size_t)k * d.P * d.W;
-    float *gp = (s == 0 ? gp0 : gp1);
-    const int shw = 3 * d.n_sh;
-    const bool both = d.use_stage[0] && d.use_stage[1];
-    const bool add_sub = (s == 0), add_out = (s == 1) || both || !d.use_stage[1];
-    const float *gA = add_out ? d.g[k] : nullptr, *gB = add_sub ? d.gs[k] : nullptr;
-    const float hc = d.hc[k];
-    const int nk = d.nk[k], nout = d.ot[k];
-    const int n_iter = (d.P + FB_ROWS - 1) / FB_ROWS;
-
-    // tile ownership
-    //  dW2_k: NT x NT tiles, 2x2 patch per wave (NT = 4), 1 tile per wave (NT = 2), wave 0 only (NT = 1)
-    constexpr int PM = (NT + 1) / 2;
-    const bool w2_on = wave < PM * PM;
-    const int w2_m0 = 2 * (wave / PM), w2_n0 = 2 * (wave % PM);
-    //  dW3_k: nout x NT tiles, tile t = ot * NT + nt' -> wave t % 4, slot t / 4
-    f32x16 acc2[4], acc3[2];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc2[q][r] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc3[q][r] = 0.f;
-    float db2 = 0.f, db3[2] = {0.f, 0.f};
-
-    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const int row_l = wave * 32 + c;               // row inside the block tile
-        const int g_raw = it * FB_ROWS + row_l;
-        const bool gvalid = g_raw < d.P;
-        const int g = gvalid ? g_raw : d.P - 1;
-        // ---- 1. trunk recompute, a^T -> LDS ----
-        float a[NT][16];
-        {
-            float eb[1][16];
-            load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
-                acc = gemm_tile<1>(fr + d.fl.F1 + (size_t)nt * 1024, eb, acc, lane);
-#pragma unroll
-                for (int r = 0; r < 16; r++) a[nt][r] = gvalid ? fmaxf(acc[r], 0.f) : 0.f;
-                lds_store_tile_T(A_T, row_l, nt, h, a[nt]);
-            }
-        }
-        // ---- 2. upstream gradient of this head's output as MFMA B operand ----
-        float gy[OTMAX][16];
-#pragma unroll
-        for (int ot = 0; ot < OTMAX; ot++)
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) gy[ot][kk] = 0.f;
-        if (gvalid) {
-            if (k < 4) {
-                if (h == 0) {
-                    for (int j = 0; j < nk; j++) {
-                        float v = 0.f;
-                        if (gA) v += gA[(size_t)g * nk + j];
-                        if (gB) v += gB[(size_t)g * nk + j];
-                        gy[0][j] = v * hc;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int cidx = 0; cidx < 6; cidx++) {
-                    const int feat = (cidx >> 2) * 32 + 8 * (cidx & 3) + 4 * h;
-                    float4 v = make_float4(0, 0, 0, 0);
-                    if (feat < shw) {
-                        if (gA) { float4 t = *reinterpret_cast<const float4 *>(gA + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                        if (gB) { float4 t = *reinterpret_cast<const float4 *>(gB + (size_t)g * shw + feat); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                    }
-                    const int ot = cidx >> 2, kk0 = 4 * (cidx & 3);
-                    gy[ot][kk0] = v.x * hc; gy[ot][kk0 + 1] = v.y * hc; gy[ot][kk0 + 2] = v.z * hc; gy[ot][kk0 + 3] = v.w * hc;
-                }
-            }
-        }
-        // ---- 3. z tiles: relu(z)^T -> LDS, keep the sign mask ----
-        unsigned long long zmask = 0ull;
-#pragma unroll 1
-        for (int nt = 0; nt < NT; nt++) {
-            f32x16 acc = bias_acc(fr + d.fl.B2 + (size_t)k * d.W, nt, h);
-            acc = gemm_tile<NT>(fr + d.fl.F2 + (((size_t)k * NT + nt) * NT) * 1024, a, acc, lane);
-            float z[16];
-            unsigned m16 = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { z[r] = gvalid ? fmaxf(acc[r], 0.f) : 0.f; m16 |= (z[r] > 0.f) ? (1u << r) : 0u; }
-            zmask |= (unsigned long long)m16 << (16 * nt);
-            lds_store_tile_T(Z_T, row_l, nt, h, z);
-        }
-        __syncthreads();
-        // ---- 4. dW3_k += (hc g_out)^T relu(z) ; db3 += column sums of hc g_out ----
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int t = wave + 4 * q;
-            if (t < nout * NT && !(d.ablate & 1)) {
-                const int ot = t / NT, ntp = t % NT;
-                const int j = ot * 32 + c;
-                const bool jok = j < nk;
-                float bsum = 0.f;
-#pragma unroll 4
-                for (int kk = 0; kk < FB_ROWS / 2; kk++) {
-                    const int rl = 2 * kk + h, gr = it * FB_ROWS + rl;
-                    float av = 0.f;
-                    if (jok && gr < d.P) {
-                        if (gA) av += gA[(size_t)gr * nk + j];
-                        if (gB) av += gB[(size_t)gr * nk + j];
-                        av *= hc;
-                    }
-                    bsum += av;
-                    acc3[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Z_T[rl * FB_LD + ntp * 32 + c], acc3[q], 0, 0, 0);
-                }
-                if (ntp == 0) db3[q] += bsum + __shfl_xor(bsum, 32);
-            }
-        }
-        __syncthreads();
-        // ---- 5. g_z tiles: g_z^T -> LDS (over relu(z)^T), g_a_k += W2^T g_z ----
-        f32x16 ga[NT];
-#pragma unroll
-        for (int i2 = 0; i2 < NT; i2++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) ga[i2][r] = 0.f;
-#pragma unroll 1
-        for (int nt = 0; nt < NT; nt++) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            if (k < 4) {
-                const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX) * 16) * 64;
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[0][kk], acc, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int ot = 0; ot < OTMAX; ot++) {
-                    const float *f3t = fr + d.fl.F3T + ((((size_t)k * NT + nt) * OTMAX + ot) * 16) * 64;
-#pragma unroll
-                    for (int kk = 0; kk < 16; kk++)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f3t[kk * 64 + lane], gy[ot][kk], acc, 0, 0, 0);
-                }
-            }
-            float gz[1][16];
-            const unsigned m16 = (unsigned)(zmask >> (16 * nt)) & 0xFFFFu;
-#pragma unroll
-            for (int r = 0; r < 16; r++) gz[0][r] = (m16 >> r) & 1u ? acc[r] : 0.f;
-            lds_store_tile_T(Z_T, row_l, nt, h, gz[0]);
-            if (!(d.ablate & 8)) {
-#pragma unroll
-                for (int i2 = 0; i2 < NT; i2++)
-                    ga[i2] = gemm_tile<1>(fr + d.fl.F2T + ((((size_t)k * NT + i2) * NT) + nt) * 1024, gz, ga[i2], lane);
-            }
-        }
-        if (gvalid) {
-#pragma unroll
-            for (int i2 = 0; i2 < NT; i2++) {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = ga[i2][r];
-                store_tile_rows(GA, d.W, g, i2, h, v);
-            }
-        }
-        __syncthreads();
-        // ---- 6. dW2_k += g_z^T a ; db2 += column sums of g_z ----
-        if (w2_on && !(d.ablate & 2)) {
-#pragma unroll 4
-            for (int kk = 0; kk < FB_ROWS / 2; kk++) {
-                const int rl = 2 * kk + h;
-                const float a0 = Z_T[rl * FB_LD + w2_m0 * 32 + c];
-                const float b0 = A_T[rl * FB_LD + w2_n0 * 32 + c];
-                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc2[0], 0, 0, 0);
-                if (NT >= 2) {
-                    const float a1 = Z_T[rl * FB_LD + (w2_m0 + 1) * 32 + c];
-                    const float b1 = A_T[rl * FB_LD + (w2_n0 + 1) * 32 + c];
-                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc2[1], 0, 0, 0);
-                    acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc2[2], 0, 0, 0);
-                    acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc2[3], 0, 0, 0);
-                }
-            }
-        }
-        if (tid < d.W && !(d.ablate & 4)) {
-            float sum = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < FB_ROWS; r++) sum += Z_T[r * FB_LD + tid];
-            db2 += sum;
-        }
-        __syncthreads();
-    }
-    // ---- flush ----
-    if (w2_on) {
-        float *dW2 = gp + pl.W2[k];
-#pragma unroll
-        for (int q = 0; q < (NT >= 2 ? 4 : 1); q++) {
-            const int mt = w2_m0 + (q >> 1), ntp = w2_n0 + (q & 1);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mi = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                atomicAdd(dW2 + (size_t)mi * d.W + ntp * 32 + c, acc2[q][r]);
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int t = wave + 4 * q;
-        if (t < nout * NT) {
-            const int ot = t / NT, ntp = t % NT;
-            float *dW3 = gp + pl.W3[k];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int j = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (j < nk) atomicAdd(dW3 + (size_t)j * d.W + ntp * 32 + c, acc3[q][r]);
-            }
-            if (ntp == 0 && h == 0 && ot * 32 + c < nk) atomicAdd(gp + pl.b3[k] + ot * 32 + c, db3[q]);
-        }
-    }
-    if (tid < d.W) atomicAdd(gp + pl.b2[k] + tid, db2);
-}
-
-template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) deform_bwd_trunk_kernel(DeformDev d, const float *GA0, const float *GA1, float *gp0, float *gp1, ParamLayout pl)
-{
-    extern __shared__ float fb_lds[];
-    float *GH_T = fb_lds;  // [128][132]  g_hid^T
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_iter = (d.P + FB_ROWS - 1) / FB_ROWS;
-    f32x16 acc1[2];  // dW1[:, TD:] tile mt = wave (NT <= 4), one per stage
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc1[q][r] = 0.f;
-    float db1[2] = {0.f, 0.f};
-    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const int row_l = wave * 32 + c;
-        const int g_raw = it * FB_ROWS + row_l;
-        const bool gvalid = g_raw < d.P;
-        const int g = gvalid ? g_raw : d.P - 1;
-        float eb[1][16];
-        load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
-        f32x16 ge;
-#pragma unroll
-        for (int r = 0; r < 16; r++) ge[r] = 0.f;
-#pragma unroll 1
-        for (int s = 0; s < 2; s++) {
-            if (!d.use_stage[s]) continue;
-            const float *fr = d.frag[s];
-            const float *GA = (s == 0 ? GA0 : GA1);
-            float gh[NT][16];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                f32x16 acc = bias_acc(fr + d.fl.HB, nt, h);
-                acc = gemm_tile<1>(fr + d.fl.F1 + (size_t)nt * 1024, eb, acc, lane);
-                float sum[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) sum[r] = 0.f;
-                for (int k = 0; k < NHEAD; k++) {
-                    if (!d.enabled[k]) continue;
-                    const float4 *row = reinterpret_cast<const float4 *>(GA + ((size_t)k * d.P + g) * d.W + nt * 32 + 4 * h);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const float4 v = row[2 * q]; sum[4 * q] += v.x; sum[4 * q + 1] += v.y; sum[4 * q + 2] += v.z; sum[4 * q + 3] += v.w; }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) gh[nt][r] = (gvalid && acc[r] > 0.f) ? sum[r] : 0.f;
-                lds_store_tile_T(GH_T, row_l, nt, h, gh[nt]);
-            }
-            ge = gemm_tile<NT>(fr + d.fl.F1T, gh, ge, lane);
-            __syncthreads();
-            if (wave < NT) {
-#pragma unroll 4
-                for (int kk = 0; kk < FB_ROWS / 2; kk++) {
-                    const int rl = 2 * kk + h, gr = it * FB_ROWS + rl;
-                    const float bv = gr < d.P ? d.emb[(size_t)gr * d.E + c] : 0.f;
-                    if (s == 0) acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(GH_T[rl * FB_LD + wave * 32 + c], bv, acc1[0], 0, 0, 0);
-                    else        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(GH_T[rl * FB_LD + wave * 32 + c], bv, acc1[1], 0, 0, 0);
-                }
-            }
-            if (tid < d.W) {
-                float sum = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < FB_ROWS; r++) sum += GH_T[r * FB_LD + tid];
-                if (s == 0) db1[0] += sum; else db1[1] += sum;
-            }
-            __syncthreads();
-        }
-        if (gvalid) {
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = ge[r];
-            store_tile_rows(d.g_emb, d.E, g, 0, h, v);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        if (!d.use_stage[s]) continue;
-        float *gp = (s == 0 ? gp0 : gp1);
-        if (wave < NT) {
-            float *dW1 = gp + pl.W1 + d.TD;
-            const int ld = d.TD + d.E;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mi = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                atomicAdd(dW1 + (size_t)mi * ld + c, s == 0 ? acc1[0][r] : acc1[1][r]);
-            }
-        }
-        if (tid < d.W) atomicAdd(gp + pl.b1 + tid, s == 0 ? db1[0] : db1[1]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // backward, weight-gradient part: dW[m][n] += sum_p G[p][m] * X[p][n], db[m] += sum_p G[p][m], split over p
 // ------------------------------------------------------------------------------------------------------------
 struct WgradJob {
@@ -3008,157 +2440,13 @@ __device__ __forceinline__ void head_wgrad_body(const HeadJob &J, int P, int spl
 template <int NP>
 __device__ __forceinline__ f32x16 mfma_bn(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16 acc)
 {
-    constexpr int SMAX = NP == 2 ? 1 : 3;
+    constexpr int SMAX = NP == 2 ? 1 : ED3_NP3_SMAX;
 #pragma unroll
     for (int sum = SMAX; sum >= 0; sum--)
 #pragma unroll
         for (int i = 0; i < NP; i++)
             if (sum - i >= 0 && sum - i < NP) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[sum - i], acc, 0, 0, 0);
     return acc;
-}
-
-template <int NP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_narrow_bn_kernel(HeadWgradArgs a)
-{
-    extern __shared__ float hj_lds[];
-    constexpr int LDG = 33, SLAB = 32 * HJ_W;                 // floats per slab
-    int jb = 0;
-    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
-    const HeadJob &J = a.job[jb];
-    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pmi = wave >> 1, pni = wave & 1;
-    const int nk = J.nk, P = a.P;
-    // LDS: [buf][z slab | a slab], then [buf][g_y slab]
-    float *gsb = hj_lds + 4 * SLAB;
-    const int chunk = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
-    const int p0 = split * chunk, p1 = min(P, p0 + chunk);
-    if (p0 >= p1) return;
-    const int nslab = (p1 - p0 + 31) / 32;
-    for (int e = tid; e < 2 * 32 * LDG; e += 256) gsb[e] = 0.f;   // pad columns stay zero
-    float w3f[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            const int k = 2 * kk + h;
-            w3f[t][kk] = (k < nk) ? J.W3[(size_t)k * HJ_W + (2 * pmi + t) * 32 + c] : 0.f;
-        }
-    f32x16 acc[2][2];
-    f32x4 acc3n = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
-    float bsum2[2] = {0.f, 0.f}, bsum3 = 0.f;
-    const bool has_g2 = J.G2 != nullptr;
-    const int gcount = 32 * nk;
-    float gv = 0.f, g2v = 0.f;
-    // slab rows [r0, r0 + 32) of relu(z) and a: 2 x 16 KB = 32 DMA instructions of 1 KB, 8 per wave; rows past the range
-    // re-read the last row (their g_y is zero)
-    auto dma = [&](int slab, int buf) {
-        const int r0 = p0 + slab * 32;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int piece = i * 4 + wave;                    // 1-KB piece = 2 rows of 128 floats
-            const int row = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
-            const size_t o = (size_t)min(r0 + row, p1 - 1) * HJ_W + col;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.ZR + o),
-                                             (__attribute__((address_space(3))) void *)(hj_lds + buf * 2 * SLAB + piece * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(J.A + o),
-                                             (__attribute__((address_space(3))) void *)(hj_lds + buf * 2 * SLAB + SLAB + piece * 256), 16, 0, 0);
-        }
-    };
-    auto load_g = [&](int slab) {
-        const int r0 = p0 + slab * 32;
-        const size_t o = (size_t)r0 * nk + min(tid, (p1 - r0) * nk - 1);
-        gv = J.G[o];
-        if (has_g2) g2v = J.G2[o];
-    };
-    auto store_g = [&](int slab, int buf) {
-        const int r0 = p0 + slab * 32;
-        if (tid < gcount) {
-            const int r = tid / nk, cc = tid - r * nk;
-            float v = gv;
-            if (has_g2) v += g2v;
-            gsb[buf * 32 * LDG + r * LDG + cc] = (r0 + r < p1) ? v * J.gscale : 0.f;
-        }
-    };
-    __syncthreads();
-    dma(0, 0);
-    load_g(0);
-    store_g(0, 0);
-    __syncthreads();
-    for (int slab = 0; slab < nslab; slab++) {
-        const int buf = slab & 1;
-        const float *zs = hj_lds + buf * 2 * SLAB, *as = zs + SLAB, *gs = gsb + buf * 32 * LDG;
-        if (slab + 1 < nslab) { dma(slab + 1, buf ^ 1); load_g(slab + 1); }
-        XSplitN<NP> gzs[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            f32x16 dd;
-#pragma unroll
-            for (int r = 0; r < 16; r++) dd[r] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++) dd = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[c * LDG + 2 * kk + h], w3f[t][kk], dd, 0, 0, 0);
-            float gz[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                gz[r] = zs[row * HJ_W + (2 * pmi + t) * 32 + c] > 0.f ? dd[r] : 0.f;
-                bsum2[t] += gz[r];
-            }
-            split_tile_n<NP>(gz, gzs[t]);
-        }
-#pragma unroll
-        for (int st = 0; st < 2; st++) {
-            bf16x8 ga0[NP], ga1[NP];
-#pragma unroll
-            for (int q = 0; q < NP; q++) { ga0[q] = gzs[0].p[q][st]; ga1[q] = gzs[1].p[q][st]; }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                float v8[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) v8[j] = as[(16 * st + 8 * (j >> 2) + 4 * h + (j & 3)) * HJ_W + (2 * pni + u) * 32 + c];
-                bf16x8 bp[NP];
-                split8_n<NP>(v8, bp);
-                acc[0][u] = mfma_bn<NP>(ga0, bp, acc[0][u]);
-                acc[1][u] = mfma_bn<NP>(ga1, bp, acc[1][u]);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            const int row = 2 * kk + h;
-            acc3n = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[row * LDG + (lane & 3)], zs[row * HJ_W + wave * 32 + c], acc3n, 0, 0, 0);
-        }
-        if (tid < nk) {
-#pragma unroll 8
-            for (int r = 0; r < 32; r++) bsum3 += gs[r * LDG + tid];
-        }
-        if (slab + 1 < nslab) store_g(slab + 1, buf ^ 1);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mi = (2 * pmi + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                atomicAdd(J.dW2 + (size_t)mi * HJ_W + (2 * pni + u) * 32 + c, acc[t][u][r]);
-            }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float v = acc3n[i] + __shfl_xor(acc3n[i], 32);
-        if (h == 0 && i < nk) atomicAdd(J.dW3 + (size_t)i * HJ_W + wave * 32 + c, v);
-    }
-    if (pni == 0) {
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const float v = bsum2[t] + __shfl_xor(bsum2[t], 32);
-            if (h == 0) atomicAdd(J.db2 + (2 * pmi + t) * 32 + c, v);
-        }
-    }
-    if (tid < nk) atomicAdd(J.db3 + tid, bsum3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3975,11 +3263,15 @@ static void fill_dev(const ed3dgs_deform_cfg *c, DeformDev &d, bool bwd)
     d.fl = frag_layout(c->W, c->E, bwd);
 }
 
-// the kept-activation backward exists for the LDS-pipelined, head-job configuration (width 128, embedding 32)
+// The fused MFMA kernels cover what the reference's configurations use: defor_depth 0 / 1, net_width <= 128, a 32-wide
+// Gaussian embedding (arguments/*: width 64 or 128).  Anything else -- deeper trunks, width 256, wider embeddings -- takes
+// the layer-by-layer fp32 path of deform_deep.hip (exact, not tuned).
+static bool use_deep(const ed3dgs_deform_cfg *c) { return c->D > 1 || c->W > 128 || c->E != 32; }
+
+// the kept-activation backward exists for the head-job configuration (width 128, <= 48 rgb outputs)
 static bool can_keep(const ed3dgs_deform_cfg *c)
 {
-    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48 && !opt(OPT_DEFORM_NO_PIPE) &&
-           !opt(OPT_DEFORM_GENERIC_WGRAD) && !opt(OPT_DEFORM_FUSED_BWD);
+    return c->W == HJ_W && c->E == 32 && 3 * c->n_sh <= 48;
 }
 
 struct Workspace {
@@ -3997,8 +3289,8 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
     obtain(p, w.fs, 2 * FS_STRIDE, 256);
     w.rows = w.ctr = nullptr;
     w.deep = nullptr;
-    if (c->D > 1) obtain(p, w.deep, deep_workspace_floats(c), 256);
-    if (bwd && c->D <= 1) {
+    if (use_deep(c)) obtain(p, w.deep, deep_workspace_floats(c), 256);
+    if (bwd && !use_deep(c)) {
         const size_t PW = (size_t)(c->P > 0 ? c->P : 0) * c->W;
         obtain(p, w.ctr, 64, 256);
         obtain(p, w.rows, (size_t)(c->P > 0 ? c->P : 0) + 64, 256);
@@ -4016,7 +3308,7 @@ static size_t carve(const ed3dgs_deform_cfg *c, bool bwd, char *base, Workspace 
 
 static bool use_b3(const ed3dgs_deform_cfg *c)
 {
-    return opt(OPT_DEFORM_BF16X3) && !opt(OPT_DEFORM_FP32_MFMA) && c->E == 32 && c->W <= 128 && !opt(OPT_DEFORM_NO_PIPE);
+    return opt(OPT_DEFORM_BF16X3) && !opt(OPT_DEFORM_FP32_MFMA) && c->E == 32 && c->W <= 128;
 }
 // How the MLP multiplies.  3 (default): every fp32 operand is split EXACTLY into three bf16 pieces and the eight piece
 // products above 2^-32 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- each product more exact than one fp32
@@ -4025,7 +3317,7 @@ static bool use_b3(const ed3dgs_deform_cfg *c)
 // (ED3DGS_DEFORM_FP32_MFMA=1).  2: two pieces, three products, ~1e-5 (ED3DGS_DEFORM_BF16X3=1, opt-in fast mode).
 static int fwd_pieces(const ed3dgs_deform_cfg *c)
 {
-    if (c->E != 32 || c->W > 128 || opt(OPT_DEFORM_NO_PIPE) || opt(OPT_DEFORM_FP32_MFMA)) return 0;
+    if (c->E != 32 || c->W > 128 || opt(OPT_DEFORM_FP32_MFMA)) return 0;
     if (opt(OPT_DEFORM_BF16X3)) return 2;
     return 3;
 }
@@ -4104,7 +3396,7 @@ template <typename F>
 static void dispatch_nt(int NT, F f)
 {
     switch (NT) { case 1: f(std::integral_constant<int, 1>()); break; case 2: f(std::integral_constant<int, 2>()); break;
-                  case 4: f(std::integral_constant<int, 4>()); break; default: f(std::integral_constant<int, 8>()); break; }
+                  default: f(std::integral_constant<int, 4>()); break; }   // width 32 / 64 / 128 (wider: deform_deep.hip)
 }
 
 }  // namespace ed3
@@ -4139,9 +3431,8 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && !params[s]) { set_error("ed3dgs_deform_forward: null params"); return ED3DGS_ERR_INVALID; }
     const bool have_sub = sub_xyz && sub_scales && sub_rot && sub_opacity && sub_sh;
     if (!have_sub && (sub_xyz || sub_scales || sub_rot || sub_opacity || sub_sh)) { set_error("ed3dgs_deform_forward: sub_* must be all set or all NULL"); return ED3DGS_ERR_INVALID; }
-    const bool deep = cfg->D > 1;   // deeper trunks: the layer-by-layer path (deform_deep.hip), which always keeps its pre-activations
+    const bool deep = use_deep(cfg);   // the layer-by-layer path (deform_deep.hip), which always keeps its pre-activations
     const bool keep = keep_activations && (deep || can_keep(cfg));
-    if (deep && cfg->E != 32) { set_error("ed3dgs_deform_forward: gaussian_embedding_dim must be 32 for defor_depth > 1"); return ED3DGS_ERR_INVALID; }
     if (workspace_bytes < carve(cfg, keep, nullptr, nullptr)) { set_error("ed3dgs_deform_forward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
@@ -4176,14 +3467,11 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     float *outs[5] = {out_xyz, out_scales, out_rot, out_opacity, out_sh};
     float *subs[5] = {sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh};
     for (int i = 0; i < 5; i++) { d.out[i] = outs[i]; d.sub[i] = have_sub ? subs[i] : nullptr; }
-    const int nstrips = (cfg->P + 31) / 32;
-    const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
-    const bool piped = d.NT <= 4 && cfg->E == 32 && !opt(OPT_DEFORM_NO_PIPE);
     const bool pf = prof_start(ED3DGS_PROF_DEFORM_FORWARD, s);
     dispatch_nt(d.NT, [&](auto nt) {
         constexpr int N = decltype(nt)::value;
-        if constexpr (N <= 4) {
-            if (piped) {  // weights shared through LDS by the block's four waves
+        {
+            {  // weights shared through LDS by the block's four waves
                 const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
                 const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
                 int n_en = 0;
@@ -4200,10 +3488,8 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
                 } else {
                     hipLaunchKernelGGL((deform_forward_pipe_kernel<N>), dim3(G), dim3(256), lds, s, d);
                 }
-                return;
             }
         }
-        hipLaunchKernelGGL((deform_forward_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
     });
     if (pf) prof_stop(ED3DGS_PROF_DEFORM_FORWARD, s);
     if (d.timing) {   // diagnostic: narrow-head tile loop of block 0 (0 weights + MFMAs + DMA pieces, 2 epilogue + kept stores, 3 output MFMAs, 4 counted wait + barrier)
@@ -4229,9 +3515,8 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            size_t workspace_bytes, int activations_kept, void *stream)
 {
     if (!validate(cfg, "ed3dgs_deform_backward")) return ED3DGS_ERR_INVALID;
-    const bool deep = cfg->D > 1;
+    const bool deep = use_deep(cfg);
     if (activations_kept && !deep && !can_keep(cfg)) { set_error("ed3dgs_deform_backward: activations_kept set for a configuration that does not keep them"); return ED3DGS_ERR_INVALID; }
-    if (cfg->E != 32) { set_error("ed3dgs_deform_backward: gaussian_embedding_dim must be 32"); return ED3DGS_ERR_INVALID; }
     if (!table || !offsets || !g_table || !g_offsets || !workspace) { set_error("ed3dgs_deform_backward: null pointer"); return ED3DGS_ERR_INVALID; }
     if ((g_base_sh_dc == nullptr) != (g_base_sh_rest == nullptr)) { set_error("ed3dgs_deform_backward: g_base_sh_dc and g_base_sh_rest must both be set or both be NULL"); return ED3DGS_ERR_INVALID; }
     if (g_base_sh_dc && !g_sh && !gs_sh) { set_error("ed3dgs_deform_backward: split dL/d SH requested without g_sh / gs_sh"); return ED3DGS_ERR_INVALID; }
@@ -4247,15 +3532,14 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     bool tail_zeroed = false;
     // the default configuration (kept activations, exact three-piece kernels) walks the active rows only
     const bool compact = !deep && activations_kept && cfg->P > 0 && cfg->P < (1 << 23) && g_embedding && fwd_pieces(cfg) == 3 && cfg->W == HJ_W && cfg->E == 32 &&
-                         3 * cfg->n_sh <= 48 && !opt(OPT_DEFORM_WGRAD_R1) && !opt(OPT_DEFORM_DW1_GENERIC) &&
-                         !opt(OPT_DEFORM_GENERIC_WGRAD) && !opt(OPT_DEFORM_FUSED_BWD) && !opt(OPT_DEFORM_DENSE_BWD);
+                         3 * cfg->n_sh <= 48 && !opt(OPT_DEFORM_DENSE_BWD);
     if (compact) {   // rows of skipped Gaussians (and the tail units' rows) of dL/d embedding start from zero
         za.p[4] = g_embedding; za.n[4] = (size_t)cfg->P * cfg->E;
         tail_zeroed = true;
     }
     if (!compact && !deep) {   // the kept data gradient's tail units add into dL/d embedding rows that must start from zero (see below): zeroed here too
         const int NTc = cfg->W / 32;
-        const bool piped_c = NTc <= 4 && cfg->E == 32 && !opt(OPT_DEFORM_NO_PIPE);
+        const bool piped_c = NTc <= 4 && cfg->E == 32;
         if (piped_c && activations_kept && cfg->P > 0 && g_embedding) {
             const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
             const int full_rounds = n_bi / G, rem_units = n_bi % G;
@@ -4326,43 +3610,16 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     }
     if (deep) {
         // (the layer-by-layer path above has produced every per-Gaussian gradient; the frame backward below is shared)
-    } else if (d.NT <= 4 && opt(OPT_DEFORM_FUSED_BWD)) {
-        // EXPERIMENTAL fused path (opt-in): weight gradients accumulated on chip, only g_a partials ([5][P][W] per
-        // stage, aliased onto the generic path's ZR region) round-trip HBM.  Parity-green, 3x less HBM traffic, but at
-        // one wave per SIMD (135 KB of LDS per block) it is MFMA-busy only 32 % of the time and currently slower
-        // (7.7 ms vs 4.9 ms at 200k Gaussians) than the dgrad + wgrad pair below.
-        const size_t lds1 = (size_t)2 * FB_ROWS * FB_LD * sizeof(float), lds2 = (size_t)FB_ROWS * FB_LD * sizeof(float);
-        const int n_iter = (cfg->P + FB_ROWS - 1) / FB_ROWS;
-        int nblk = 0;
-        for (int st = 0; st < 2; st++) for (int k = 0; k < NHEAD; k++) nblk += (cfg->use_stage[st] && d.enabled[k]);
-        const int G1 = std::max(1, std::min(n_iter, 256 / std::max(nblk, 1)));
-        const int G2 = std::max(1, std::min(n_iter, 512));
-        bool okl = true;
-        dispatch_nt(d.NT, [&](auto nt) {
-            constexpr int N = decltype(nt)::value;
-            if constexpr (N <= 4) {
-                okl = okl && check_hip(hipFuncSetAttribute((const void *)deform_bwd_head_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "set LDS size");
-                okl = okl && check_hip(hipFuncSetAttribute((const void *)deform_bwd_trunk_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), "set LDS size");
-                if (okl) {
-                    hipLaunchKernelGGL((deform_bwd_head_kernel<N>), dim3(G1, NHEAD, 2), dim3(256), lds1, s, d, w.ZR[0], w.ZR[1], gparams[0], gparams[1], pl);
-                    hipLaunchKernelGGL((deform_bwd_trunk_kernel<N>), dim3(G2), dim3(256), lds2, s, d, (const float *)w.ZR[0], (const float *)w.ZR[1], gparams[0], gparams[1], pl);
-                }
-            }
-        });
-        if (!okl || !check_hip(hipGetLastError(), "deform fused backward")) return ED3DGS_ERR_HIP;
     } else {
-        const int nstrips = (cfg->P + 31) / 32;
-        const int blocks = std::min((nstrips + 3) / 4, 256 * 8);
-        const bool piped = d.NT <= 4 && cfg->E == 32 && !opt(OPT_DEFORM_NO_PIPE);
         // head jobs (g_z re-formed inside the weight-gradient kernel): width 128, head outputs <= 48
-        const bool head_jobs = piped && cfg->W == HJ_W && 3 * cfg->n_sh <= 48 && !opt(OPT_DEFORM_GENERIC_WGRAD);
+        const bool head_jobs = cfg->W == HJ_W && 3 * cfg->n_sh <= 48;
         d.store_gz = head_jobs ? 0 : 1;
         bool okp = true;
         const bool pd = prof_start(ED3DGS_PROF_DEFORM_DGRAD, s);
         dispatch_nt(d.NT, [&](auto nt) {
             constexpr int N = decltype(nt)::value;
-            if constexpr (N <= 4) {
-                if (piped && activations_kept) {
+            {
+                if constexpr (N == HJ_W / 32) if (activations_kept) {   // (kept activations exist at width 128 only: can_keep)
                     const size_t lds = (size_t)2 * (N + OTMAX) * 1024 * sizeof(float);
                     const int n_bi = (cfg->P + 127) / 128, G = std::min(n_bi, 512);
                     d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
@@ -4382,14 +3639,13 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                     else hipLaunchKernelGGL((deform_dgrad_kept_kernel<N>), dim3(G), dim3(256), lds, s, d);
                     return;
                 }
-                if (piped) {
+                {   // stateless: re-forms the forward activations
                     const size_t lds = (size_t)2 * (2 * N + OTMAX) * 1024 * sizeof(float);
                     okp = check_hip(hipFuncSetAttribute((const void *)deform_dgrad_pipe_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "set LDS size");
                     if (okp) hipLaunchKernelGGL((deform_dgrad_pipe_kernel<N>), dim3(std::min((cfg->P + 127) / 128, 512)), dim3(256), lds, s, d);
                     return;
                 }
             }
-            hipLaunchKernelGGL((deform_dgrad_kernel<N>), dim3(blocks), dim3(256), 0, s, d);
         });
         if (pd) prof_stop(ED3DGS_PROF_DEFORM_DGRAD, s);
         if (!okp) return ED3DGS_ERR_HIP;
@@ -4410,7 +3666,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 }
         };
         const bool both = cfg->use_stage[0] && cfg->use_stage[1];
-        const bool dw1_stream = cfg->W == 128 && cfg->E == 32 && !opt(OPT_DEFORM_DW1_GENERIC);
+        const bool dw1_stream = cfg->W == 128 && cfg->E == 32;
         Dw1Args dw1;
         std::memset(&dw1, 0, sizeof dw1);
         dw1.P = cfg->P;
@@ -4506,7 +3762,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         const bool b3 = use_b3(cfg);
         const int sub = wide ? ED3DGS_PROF_DEFORM_WGRAD_WIDE : ED3DGS_PROF_DEFORM_WGRAD_NARROW;
         const bool ps = prof_start(sub, s);
-        const bool tr_form = fwd_pieces(cfg) == 3 && !opt(OPT_DEFORM_WGRAD_R1) && cfg->P < (1 << 23);   // 32-bit element offsets in these kernels   // round-2 kernels (exact three-piece mode)
+        const bool tr_form = fwd_pieces(cfg) == 3 && cfg->P < (1 << 23);   // exact three-piece mode (32-bit element offsets in these kernels; beyond 2^23 Gaussians the f32-MFMA kernels below take over)
         if (tr_form) {
             static unsigned long long *wg_timing = nullptr;
             if (opt(OPT_WG_TIMING) && !wg_timing) (void)hipMalloc((void **)&wg_timing, 2 * 32 * sizeof(unsigned long long));
@@ -4538,11 +3794,7 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                 hipLaunchKernelGGL((deform_head_wgrad_kernel<true, false>), dim3(nblk), dim3(256), lds, s, ha);
             }
         } else {
-            if (fwd_pieces(cfg) == 3) {
-                const size_t ldsn = (size_t)(4 * 32 * HJ_W + 2 * 32 * 33) * sizeof(float);   // two (z, a) slab pairs + two g_y slabs
-                if (!check_hip(hipFuncSetAttribute((const void *)deform_head_wgrad_narrow_bn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn), "set LDS size")) return ED3DGS_ERR_HIP;
-                hipLaunchKernelGGL(deform_head_wgrad_narrow_bn_kernel<3>, dim3(nblk), dim3(256), ldsn, s, ha);
-            } else if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
+            if (b3) hipLaunchKernelGGL((deform_head_wgrad_kernel<false, true>), dim3(nblk), dim3(256), lds, s, ha);
             else hipLaunchKernelGGL((deform_head_wgrad_kernel<false, false>), dim3(nblk), dim3(256), lds, s, ha);
         }
         if (ps) prof_stop(sub, s);

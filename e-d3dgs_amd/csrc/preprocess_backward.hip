@@ -380,6 +380,8 @@ __device__ __forceinline__ void preprocess_backward_body(
 // thread = Gaussian.  dL_dsh is the largest output (192 B per Gaussian at degree 3); written per thread it is 48
 // stores of 4 bytes at a 192-byte lane stride.  The rows are staged in LDS (odd row stride: conflict-free) and the
 // block writes its 256 rows -- contiguous in memory -- as one coalesced stream.
+// (Round 3: 153 registers = 3 waves per SIMD, and the 50 KB of SH staging per block allow 3 blocks per CU = the same 3 waves:
+// asking the allocator for 4 / 5 waves (128 / 96 registers) spills and LOSES: 63 -> 72 / 91 us at 200k.)
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,

@@ -8,8 +8,11 @@ namespace ed3 {
 
 // The depth + normal variant (training's FTT) is held to 96 registers = 5 waves per SIMD (102 -> 4 without the bound; 48 bytes of
 // scratch outside the pair loop): 0.264 -> 0.256 ms at C3.  The same bound on K7 (136 -> 128 registers, 4 waves) LOST 3 %.
+#ifndef ED3_K6_WAVES
+#define ED3_K6_WAVES 5
+#endif
 template <bool COORD, bool DEPTH>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COORD && DEPTH) ? 5 : 1), ((!COORD && DEPTH) ? 5 : 8)))) render_forward_kernel(
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COORD && DEPTH) ? ED3_K6_WAVES : 1), ((!COORD && DEPTH) ? ED3_K6_WAVES : 8)))) render_forward_kernel(
     int W, int H, int gx, const uint32_t *__restrict__ tile_order, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, const float4 *__restrict__ rec_coord, float focal_x, float focal_y,
     const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_coord,

@@ -80,11 +80,13 @@ def test_lists_bit_exact(case):
     print(case, "instances", fw["num_rendered"], "visible", int((fw["radii"] > 0).sum()))
 
 
-def test_library_depth_sort_agrees(libopt):
-    """ED3DGS_SORT_LIBRARY=1: rocPRIM's sort in place of the hand-written three-pass radix sort of binning level 1."""
+@pytest.mark.parametrize("case", ["giants-1080p", "pile", "identical-depths", "deep-range-9k", "one-row", "1025-rows"])
+def test_handwritten_depth_sort_agrees(case, libopt):
+    """ED3DGS_SORT_HANDWRITTEN=1: the three-pass radix sort of csrc/binning.hip in place of the library's sort for binning level 1
+    (opt-in: bit-identical, fewer launches, but slower at 200k keys -- DESIGN.md)."""
     _need_gpu()
-    libopt("SORT_LIBRARY", 1)
-    _lists_equal(_giants(util.scene_inputs(20000, 1100, 1604, scene_seed=19, cam_seed=20), 10, 30.0), 2)
+    libopt("SORT_HANDWRITTEN", 1)
+    _lists_equal(*CASES[case]())
 
 
 @pytest.mark.parametrize("switch,path", [("BIN_ONE_LEVEL", 1), ("BIN_RADIX", 0)])

@@ -352,10 +352,16 @@ def test_train_style_steps_match_the_unpacked_module(D):
     names = [n for n, _ in net.named_parameters()]
     for step in range(3):
         t = 0.2 + 0.3 * step
+        mg = []
+        fin, _ = T.forward(ref_sd, a, D, 150, *[b.double() for b in base], emb.double(), t, None, 20000, 30, 30, margin_out=mg)
+        # Gaussians on a ReLU kink (a pre-activation within fp32 rounding of zero) have a discontinuous gradient: out of the loss
+        # on both sides, as in test_against_torch_restatement (one flipped unit of one Gaussian is 1 / P of a frame-level gradient)
+        off_kink = (mg[0] > 1e-6).float()
+        assert off_kink.mean() > 0.9
+        wk = [w * off_kink.reshape(-1, *([1] * (w.dim() - 1))) for w in ws]
+        sum((o.reshape(w.shape) * w.double()).sum() for o, w in zip(fin, wk)).backward()
         outs = net(*[b.cuda() for b in base[:4]], t, None, _PC(emb.cuda()), None, base[4].cuda(), iter=20000, num_down_emb_c=30, num_down_emb_f=30)
-        sum((o * w.cuda()).sum() for o, w in zip(outs[:5], ws)).backward()
-        fin, _ = T.forward(ref_sd, a, D, 150, *[b.double() for b in base], emb.double(), t, None, 20000, 30, 30)
-        sum((o.reshape(w.shape) * w.double()).sum() for o, w in zip(fin, ws)).backward()
+        sum((o * w.cuda()).sum() for o, w in zip(outs[:5], wk)).backward()
         for n in names:
             gr, gg = ref_sd[n].grad, dict(net.named_parameters())[n].grad
             if gr is None or float(gr.abs().max()) == 0:
