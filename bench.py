@@ -558,10 +558,8 @@ def main():
                  "frac": it_per_s * K7_ISSUE_CYCLES_PER_ITER / (1024 * 2.4e9), "pairs_per_s": k7_work[1] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                  "note": "vector-instruction issue cycles the visited iterations need / cycles the 1024 SIMDs offer in the launch; the "
                          "counts from a separate pass over the first %d items (counting slows K7 to %.3f ms per launch; that is not the time used)" % (n_count, k7_count_ms)}
-    valu_roof["quadrants_with_a_blended_pixel_hist_1_2_3_4"] = k7_work[4:8]
-    valu_roof["mean_quadrants_per_iteration"] = (sum((i + 1) * k7_work[4 + i] for i in range(4)) / k7_work[0]) if k7_work[0] else 0.0
-    valu_roof["mean_top_bottom_halves_per_iteration"] = k7_work[8] / k7_work[0] if k7_work[0] else 0.0
-    valu_roof["mean_left_right_halves_per_iteration"] = k7_work[9] / k7_work[0] if k7_work[0] else 0.0
+    valu_roof["quadrant_entries_queued_per_launch"] = k7_work[4]   # (entry, quadrant) pairs the four quadrants' sub-lists hold
+    valu_roof["quadrant_entries_per_iteration"] = k7_work[4] / k7_work[0] if k7_work[0] else 0.0   # of 4 slots
     # K6 against the same roof (ISA of render_forward_kernel<false,true>, tools/isa.sh: a list entry kept by the tile-level reject
     # costs 44 four-cycle vector instructions + 4 v_exp_f32 for the per-pixel tests; one that blends anything, 86 more)
     K6_TEST_CYCLES, K6_BLEND_CYCLES = 44 * 4 + 4 * 8, 86 * 4

@@ -73,6 +73,43 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[NV], int lane)
     return z;
 }
 
+// The same butterfly confined to a DPP row of 16 lanes (= one quadrant of the tile, raster_common.h): on entry every lane holds
+// NV partial sums; on return lane l holds the ROW's total of value (l & 15) in z[0] (and of value 16 + (l & 15) in z[1] for
+// NV = 32).  Four DPP steps, no cross-row traffic: each quadrant reduces the gradients of ITS Gaussian.
+template <int NV>
+__device__ __forceinline__ void row_transpose_reduce(float (&v)[NV], int lane, float (&z)[NV / 16])
+{
+    static_assert(NV == 16 || NV == 32, "NV");
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float a[NV / 2];
+#pragma unroll
+    for (int i = 0; i < NV / 2; i++) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+        const float send = b0 ? v[2 * i] : v[2 * i + 1];
+        a[i] = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]
+    }
+    float b[NV / 4];
+#pragma unroll
+    for (int i = 0; i < NV / 4; i++) {
+        const float keep = b1 ? a[2 * i + 1] : a[2 * i];
+        const float send = b1 ? a[2 * i] : a[2 * i + 1];
+        b[i] = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1]
+    }
+    float c[NV / 8];
+#pragma unroll
+    for (int i = 0; i < NV / 8; i++) {
+        const float keep = b2 ? b[2 * i + 1] : b[2 * i];
+        const float send = b2 ? b[2 * i] : b[2 * i + 1];
+        c[i] = keep + dpp_mov<0x124>(send);  // row_ror:4
+    }
+#pragma unroll
+    for (int i = 0; i < NV / 16; i++) {
+        const float keep = b3 ? c[2 * i + 1] : c[2 * i];
+        const float send = b3 ? c[2 * i] : c[2 * i + 1];
+        z[i] = keep + dpp_mov<0x128>(send);  // row_ror:8
+    }
+}
+
 template <bool COORD, bool DEPTH>
 __global__ void __launch_bounds__(64) render_backward_kernel(
     int W, int H, int gx, const uint32_t *__restrict__ tile_order, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -84,14 +121,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dmdepth, const float *__restrict__ dL_dalpha,
     const float *__restrict__ dL_dnormal, float *__restrict__ grec, float *__restrict__ grec_coord,
     unsigned long long *__restrict__ counters)   // measurement only (bench.py): [0] visited (tile, Gaussian) iterations, [1] blended
-                                                  // pairs, [2] staged list entries, [3] entries kept by the tile-level reject,
-                                                  // [4..7] visited iterations whose blended pixels lie in 1 / 2 / 3 / 4 of the tile's
-                                                  // 8x8 quadrants, [8] / [9] sums over visited iterations of the 16x8 (top / bottom)
-                                                  // and 8x16 (left / right) halves with a blended pixel; NULL = off
+                                                  // pairs, [2] staged list entries, [3] entries kept for at least one quadrant,
+                                                  // [4] (entry, quadrant) pairs queued; NULL = off
 {
     constexpr bool GEO = COORD || DEPTH;
     constexpr int NV = COORD ? 32 : 16;
-    unsigned n_iter = 0, n_pair = 0, n_staged = 0, n_kept = 0, n_quad[4] = {0, 0, 0, 0}, n_tb = 0, n_lr = 0;
+    unsigned n_iter = 0, n_pair = 0, n_staged = 0, n_kept = 0, n_qpairs = 0;
     __shared__ float4 s_rec[64 * 4];
     __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
     __shared__ uint32_t s_id[64];
@@ -99,8 +134,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const int tile = (int)tile_order[blockIdx.x];   // longest tile lists first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
-    const int px0 = tx * TILE + (lane & 3) * 4;
-    const int py = ty * TILE + (lane >> 2);
+    const int myq = lane >> 4, li = lane & 15;                       // quadrant-major pixel ownership (raster_common.h)
+    const uint32_t jshift = 8u * (uint32_t)myq;
+    const int px0 = tx * TILE + 8 * (myq & 1) + 4 * (li & 1);
+    const int py = ty * TILE + 8 * (myq >> 1) + (li >> 1);
     const size_t HW = (size_t)H * W;
     const int nvalid = (py < H) ? max(0, min(4, W - px0)) : 0;
     const bool vec = (nvalid == 4) && ((W & 3) == 0);
@@ -223,13 +260,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     uint32_t lmax = max(max(last[0], last[1]), max(last[2], last[3]));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off));
-    const int tile_max = (int)lmax;
+    const int tile_max = __builtin_amdgcn_readfirstlane((int)lmax);   // (wave-uniform by construction; tell the compiler: the chunk masks below stay in scalar registers)
     const float hW = 0.5f * W, hH = 0.5f * H;
+    // ... and of each quadrant: entries at or behind it are dropped from that quadrant's sub-list
+    uint32_t qm = max(max(last[0], last[1]), max(last[2], last[3]));
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) qm = max(qm, (uint32_t)__shfl_xor((int)qm, off));
+    const int qmax0 = __builtin_amdgcn_readlane((int)qm, 0), qmax1 = __builtin_amdgcn_readlane((int)qm, 16);
+    const int qmax2 = __builtin_amdgcn_readlane((int)qm, 32), qmax3 = __builtin_amdgcn_readlane((int)qm, 48);
 
     for (int top = tile_max; top > 0; top -= 64) {
         __syncthreads();
         const int cnt = min(64, top);
-        bool keep = false;
+        unsigned keepq = 0;   // quadrants of the tile in which this lane's entry can reach alpha >= 1/255
         if (lane < cnt) {
             const uint32_t id = point_list[range.x + (uint32_t)(top - 1 - lane)];
             const float4 *src = rec + (size_t)id * 4;
@@ -237,23 +280,39 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             s_id[lane] = id;
             s_rec[lane * 4 + 0] = q0;
             s_rec[lane * 4 + 1] = q1;
-            keep = tile_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0, tile_x0 + (TILE - 1), tile_y0 + (TILE - 1));
-            if (keep) {   // the rest of the record only for entries the inner loop will visit
+            keepq = quadrants_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
+            if (keepq) {   // the rest of the record only for entries the inner loop will visit
                 s_rec[lane * 4 + 2] = src[2];
                 if (GEO) s_rec[lane * 4 + 3] = src[3];
             }
-            if (COORD && keep) {
+            if (COORD && keepq) {
                 const float4 *sc = rec_coord + (size_t)id * 3;
                 s_recc[lane * 3 + 0] = sc[0]; s_recc[lane * 3 + 1] = sc[1]; s_recc[lane * 3 + 2] = sc[2];
             }
         }
         __syncthreads();
-        // entries that cannot reach alpha >= 1/255 anywhere in the tile are never visited (raster_common.h)
-        unsigned long long live = __ballot(keep);
-        if (counters) { n_staged += (unsigned)cnt; n_kept += (unsigned)__popcll(live); }
-        while (live) {
-            const int j = __builtin_ctzll(live);
-            live &= live - 1;
+        // per quadrant: the chunk's entries that can contribute inside its box, back to front (raster_common.h); every iteration
+        // each quadrant takes the next entry of ITS OWN sub-list, so up to four Gaussians are differentiated per iteration
+        unsigned long long live0 = __ballot(keepq & 1u), live1 = __ballot(keepq & 2u), live2 = __ballot(keepq & 4u), live3 = __ballot(keepq & 8u);
+        {   // entry j sits at list position top - 1 - j: a quadrant needs only the positions below its own largest last contributor
+            auto behind = [&](int qmax) { const int nb = top - qmax; return nb <= 0 ? ~0ull : nb >= 64 ? 0ull : ~((1ull << nb) - 1ull); };
+            live0 &= behind(qmax0); live1 &= behind(qmax1); live2 &= behind(qmax2); live3 &= behind(qmax3);
+        }
+        if (counters) {
+            n_staged += (unsigned)cnt; n_kept += (unsigned)__popcll(live0 | live1 | live2 | live3);
+            n_qpairs += (unsigned)(__popcll(live0) + __popcll(live1) + __popcll(live2) + __popcll(live3));
+        }
+        while (live0 | live1 | live2 | live3) {
+            // next entry of each quadrant's sub-list (-1: none left), packed into one scalar: a lane picks its byte
+            const int j0 = __ffsll(live0) - 1, j1 = __ffsll(live1) - 1, j2 = __ffsll(live2) - 1, j3 = __ffsll(live3) - 1;
+            live0 &= live0 - 1; live1 &= live1 - 1; live2 &= live2 - 1; live3 &= live3 - 1;
+            const uint32_t jpack = (uint32_t)(j0 & 255) | (uint32_t)(j1 & 255) << 8 | (uint32_t)(j2 & 255) << 16 | (uint32_t)(j3 & 255) << 24;
+            const int jsel = (int)(jpack >> jshift & 255u);
+            const bool act = jsel != 255;                    // this lane's quadrant still has an entry in the chunk
+            // (an idle quadrant reads the record of a quadrant that is not idle: a kept entry, i.e. finite values -- its lanes
+            // multiply them by alpha = 0, and a slot nobody staged could hold a NaN)
+            const int jany = j0 >= 0 ? j0 : j1 >= 0 ? j1 : j2 >= 0 ? j2 : j3;
+            const int j = act ? jsel : jany;
             const uint32_t k = (uint32_t)(top - 1 - j);  // 0-based position in the tile list
             const float4 r0 = s_rec[j * 4 + 0];          // x, y, cx, cy
             const float4 r1 = s_rec[j * 4 + 1];          // cz, w, r, g
@@ -268,24 +327,18 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             for (int q = 0; q < 2; q++) {   // pixel pairs: the same packed evaluation as the forward's (raster_common.h)
                 dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
                 const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
-                const bool v0 = (k < last[2 * q]) && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
-                const bool v1 = (k < last[2 * q + 1]) && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
+                const bool v0 = act && (k < last[2 * q]) && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
+                const bool v1 = act && (k < last[2 * q + 1]) && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
                 any_valid |= v0 | v1;
                 alpha[2 * q] = v0 ? ap.alpha.x : 0.f; alpha[2 * q + 1] = v1 ? ap.alpha.y : 0.f;
                 G[2 * q] = v0 ? ap.G.x : 0.f; G[2 * q + 1] = v1 ? ap.G.y : 0.f;
                 med[2 * q] = v0 && (k + 1u == maxc[2 * q]); med[2 * q + 1] = v1 && (k + 1u == maxc[2 * q + 1]);
             }
-            if (!__any(any_valid)) continue;
+            const unsigned long long anyb = __ballot(any_valid);
+            if (!anyb) continue;
             if (counters) {   // per lane; summed over the wave once, at the end of the tile
                 n_iter++;
                 n_pair += (alpha[0] > 0.f) + (alpha[1] > 0.f) + (alpha[2] > 0.f) + (alpha[3] > 0.f);
-                // quadrant of a lane's pixels: x half = bit 1 of the lane (lanes 4 m + {0,1} own columns 0..7), y half = bit 5
-                const unsigned long long bal = __ballot(any_valid);
-                const unsigned long long LEFT = 0x3333333333333333ull, TOP = 0x00000000FFFFFFFFull;
-                const int q00 = (bal & LEFT & TOP) != 0, q10 = (bal & ~LEFT & TOP) != 0, q01 = (bal & LEFT & ~TOP) != 0, q11 = (bal & ~LEFT & ~TOP) != 0;
-                n_quad[q00 + q10 + q01 + q11 - 1]++;
-                n_tb += (q00 | q10) + (q01 | q11);
-                n_lr += (q00 | q01) + (q10 | q11);
             }
 
             const float4 r2 = s_rec[j * 4 + 2];  // b, tongue, ts, rpx
@@ -397,12 +450,14 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             acc[G_MX] = mx;
             acc[G_MY] = my;
             acc[G_MZ] = mz;
-            const float z = wave_transpose_reduce<NV>(acc, lane);
-            const uint32_t id = s_id[j];
-            if (lane < 16) {
-                atomicAdd(grec + (size_t)id * GREC + lane, z);
-            } else if (COORD && lane < 16 + 9) {
-                atomicAdd(grec_coord + (size_t)id * GREC + (lane - 16), z);
+            // each quadrant (DPP row) reduces the record of its own Gaussian; a quadrant in which no pixel blended adds nothing
+            float z[NV / 16];
+            row_transpose_reduce<NV>(acc, lane, z);
+            const bool qany = (anyb >> (16 * myq) & 0xFFFFull) != 0ull;
+            if (act && qany) {
+                const uint32_t id = s_id[j];
+                atomicAdd(grec + (size_t)id * GREC + li, z[0]);
+                if (COORD && li < 9) atomicAdd(grec_coord + (size_t)id * GREC + li, z[NV / 16 - 1]);
             }
         }
     }
@@ -413,8 +468,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     if (counters && lane == 0) {
         atomicAdd(counters + 0, (unsigned long long)n_iter); atomicAdd(counters + 1, (unsigned long long)n_pair);
         atomicAdd(counters + 2, (unsigned long long)n_staged); atomicAdd(counters + 3, (unsigned long long)n_kept);
-        for (int q = 0; q < 4; q++) atomicAdd(counters + 4 + q, (unsigned long long)n_quad[q]);
-        atomicAdd(counters + 8, (unsigned long long)n_tb); atomicAdd(counters + 9, (unsigned long long)n_lr);
+        atomicAdd(counters + 4, (unsigned long long)n_qpairs);
     }
 }
 

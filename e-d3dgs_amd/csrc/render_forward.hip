@@ -6,10 +6,11 @@
 
 namespace ed3 {
 
-// The depth + normal variant (training's FTT) is held to 96 registers = 5 waves per SIMD (102 -> 4 without the bound; 48 bytes of
-// scratch outside the pair loop): 0.264 -> 0.256 ms at C3.  The same bound on K7 (136 -> 128 registers, 4 waves) LOST 3 %.
+// Round 3: with the exact alpha evaluation and the quadrant scheduling the 96-register bound of round 2 (5 waves per SIMD)
+// costs 80 bytes of scratch, some of it inside the blend loop: 4 waves (128 registers, no scratch) measured 0.284 vs 0.298 ms,
+// 6 waves 0.574 ms (tools/ab_build.sh k6w4 -DED3_K6_WAVES=4).
 #ifndef ED3_K6_WAVES
-#define ED3_K6_WAVES 5
+#define ED3_K6_WAVES 4
 #endif
 template <bool COORD, bool DEPTH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COORD && DEPTH) ? ED3_K6_WAVES : 1), ((!COORD && DEPTH) ? ED3_K6_WAVES : 8)))) render_forward_kernel(
@@ -31,8 +32,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
     const int tile = (int)tile_order[blockIdx.x];   // longest tile lists first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
-    const int px0 = tx * TILE + (lane & 3) * 4;
-    const int py = ty * TILE + (lane >> 2);
+    const int myq = lane >> 4, li = lane & 15;                       // quadrant-major pixel ownership (raster_common.h)
+    const uint32_t jshift = 8u * (uint32_t)myq;
+    const int px0 = tx * TILE + 8 * (myq & 1) + 4 * (li & 1);
+    const int py = ty * TILE + 8 * (myq >> 1) + (li >> 1);
     const size_t HW = (size_t)H * W;
     const int nvalid = (py < H) ? max(0, min(4, W - px0)) : 0;  // pixels of this lane inside the image
     const bool vec = (nvalid == 4) && ((W & 3) == 0);
@@ -64,30 +67,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
         if (__all(done[0] && done[1] && done[2] && done[3])) break;
         __syncthreads();
         const int k = base + lane;
-        bool keep = false;
+        unsigned keepq = 0;   // quadrants of the tile in which this lane's entry can reach alpha >= 1/255
         if (k < n) {
             const uint32_t id = point_list[range.x + k];
             const float4 *src = rec + (size_t)id * 4;
             const float4 q0 = src[0], q1 = src[1];
             s_rec[lane * 4 + 0] = q0;
             s_rec[lane * 4 + 1] = q1;
-            keep = tile_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0, tile_x0 + (TILE - 1), tile_y0 + (TILE - 1));
-            if (keep) {   // the rest of the record only for entries the inner loop will visit
+            keepq = quadrants_may_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_x0, tile_y0);
+            if (keepq) {   // the rest of the record only for entries the inner loop will visit
                 if (GEO) { s_rec[lane * 4 + 2] = src[2]; s_rec[lane * 4 + 3] = src[3]; }
                 else     { s_rec[lane * 4 + 2] = src[2]; }
             }
-            if (COORD && keep) {
+            if (COORD && keepq) {
                 const float4 *sc = rec_coord + (size_t)id * 3;
                 s_recc[lane * 3 + 0] = sc[0]; s_recc[lane * 3 + 1] = sc[1]; s_recc[lane * 3 + 2] = sc[2];
             }
         }
         __syncthreads();
-        // entries that cannot reach alpha >= 1/255 anywhere in the tile are never visited (raster_common.h)
-        unsigned long long live = __ballot(keep);
-        if (counters) { n_staged += (unsigned)min(64, n - base); n_kept += (unsigned)__popcll(live); }
-        while (live) {
-            const int j = __builtin_ctzll(live);
-            live &= live - 1;
+        // per quadrant: the chunk's entries that can contribute inside its box, in list order (raster_common.h); every
+        // iteration each quadrant takes the next entry of ITS OWN sub-list
+        unsigned long long live0 = __ballot(keepq & 1u), live1 = __ballot(keepq & 2u), live2 = __ballot(keepq & 4u), live3 = __ballot(keepq & 8u);
+        if (counters) { n_staged += (unsigned)min(64, n - base); n_kept += (unsigned)__popcll(live0 | live1 | live2 | live3); }
+        while (live0 | live1 | live2 | live3) {
+            // next entry of each quadrant's sub-list (-1: none left), packed into one scalar: a lane picks its byte
+            const int j0 = __ffsll(live0) - 1, j1 = __ffsll(live1) - 1, j2 = __ffsll(live2) - 1, j3 = __ffsll(live3) - 1;
+            live0 &= live0 - 1; live1 &= live1 - 1; live2 &= live2 - 1; live3 &= live3 - 1;
+            const uint32_t jpack = (uint32_t)(j0 & 255) | (uint32_t)(j1 & 255) << 8 | (uint32_t)(j2 & 255) << 16 | (uint32_t)(j3 & 255) << 24;
+            const int jsel = (int)(jpack >> jshift & 255u);
+            const bool act = jsel != 255;                    // this lane's quadrant still has an entry in the chunk
+            // (an idle quadrant reads the record of a quadrant that is not idle: a kept entry, i.e. finite values -- its lanes
+            // multiply them by alpha = 0, and a slot nobody staged could hold a NaN)
+            const int jany = j0 >= 0 ? j0 : j1 >= 0 ? j1 : j2 >= 0 ? j2 : j3;
+            const int j = act ? jsel : jany;
             const uint32_t contributor = (uint32_t)(base + j + 1);
             const float4 r0 = s_rec[j * 4 + 0];  // x, y, cx, cy
             const float4 r1 = s_rec[j * 4 + 1];  // cz, w, r, g
@@ -101,8 +113,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
                 dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
                 const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
                 alpha[2 * q] = ap.alpha.x; alpha[2 * q + 1] = ap.alpha.y;
-                valid[2 * q] = !done[2 * q] && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
-                valid[2 * q + 1] = !done[2 * q + 1] && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
+                valid[2 * q] = act && !done[2 * q] && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
+                valid[2 * q + 1] = act && !done[2 * q + 1] && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
                 any_valid |= valid[2 * q] | valid[2 * q + 1];
             }
             if (!__any(any_valid)) continue;
@@ -148,8 +160,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
                 T[p] = blend ? test_T : T[p];
                 last[p] = blend ? contributor : last[p];
             }
-            if (__any(any_term)) {
-                if (__all(done[0] && done[1] && done[2] && done[3])) { finished = true; break; }
+            if (__any(any_term)) {   // a quadrant whose 64 pixels are all done drops the rest of its sub-list
+                const unsigned long long dn = __ballot(done[0] && done[1] && done[2] && done[3]);
+                if (dn == ~0ull) { finished = true; break; }
+                if ((dn & 0xFFFFull) == 0xFFFFull) live0 = 0ull;
+                if ((dn >> 16 & 0xFFFFull) == 0xFFFFull) live1 = 0ull;
+                if ((dn >> 32 & 0xFFFFull) == 0xFFFFull) live2 = 0ull;
+                if ((dn >> 48) == 0xFFFFull) live3 = 0ull;
             }
         }
     }
