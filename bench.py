@@ -407,6 +407,8 @@ def main():
     log("timed region")
     L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(1 << dom))
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]   # step boundaries on the launch stream
+    import gc
+    gc.collect(); gc.disable()   # a cyclic-GC pause of the interpreter inside the timed region showed as a 6-ms step (of 2.2)
     t0 = time.perf_counter()
     marks[0].record()
     for k in range(a.steps):
@@ -415,6 +417,7 @@ def main():
     step.drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
     slot_ms, slot_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(slot_ms, slot_n)
