@@ -351,6 +351,15 @@ def main():
     my_items = D.shard_items(max(n_items, world), rank, world)
     item_at = lambda k: D.strided_item(my_items, k) % n_items   # coprime stride: a 20-step run visits every camera
     ceiling = hbm_ceiling(device) if rank == 0 else None
+    mfma_ceiling = None
+    if rank == 0:   # what the matrix pipe sustains on this box (untimed): the spec peak the roofline uses is not a sustained rate
+        tf, cms = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        torch.cuda.synchronize()
+        if L.ed3dgs_measure_mfma_ceiling(ctypes.c_int(4000), ctypes.byref(tf), ctypes.byref(cms)) == 0:
+            mfma_ceiling = {"bf16_32x32x16_TFLOPs": tf.value, "ms": cms.value, "spec_dense_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+                            "note": "v_mfma_f32_32x32x16_bf16 back to back on random operands in registers, two waves per SIMD on all 1024 "
+                                    "SIMDs, no memory traffic: the rate the chip holds at its power limit (the clock drops under the matrix "
+                                    "load); `peak` in the roofline stays the spec figure"}
 
     # ---- untimed: warm-up + algorithmic-byte bookkeeping of the items the timed region will visit ----
     _C.KEEP_LAST = True
@@ -598,6 +607,7 @@ def main():
                 "traffic": pmc.get(nm.split(" ")[0]), "traffic_source": traffic_source,
                 "algorithmic_flops_per_launch": 2.0 * mac * rows_dom, "executed_matrix_flops_per_launch": 2.0 * mac * rows_dom * pr,
                 "fp32_equivalent_TFLOPs": eq, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
+                "frac_of_measured_sustained_rate": (eq * pr / mfma_ceiling["bf16_32x32x16_TFLOPs"]) if (mfma_ceiling and pr > 1) else None,
                 "note": ("dominant kernel of the step by time.  Algorithmic flops = 2 * %d MAC per Gaussian (fp32 multiplies); " % mac) +
                         ("each fp32 multiply runs as %d exact bf16 piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, "
                          "so `achieved` = executed piece-product flops / launch time against the dense bf16 MFMA peak; "
@@ -619,6 +629,7 @@ def main():
                   "step_ms_median_per_rank": rank_step_ms, "wall_ms_per_step_per_rank": rank_wall_ms,
                   "mean_num_rendered_per_rank": rank_num_rendered,
                   "rank0_items_timed": items_timed, "rank0_cameras_timed": cams_timed},
+        "mfma_ceiling_measured": mfma_ceiling,
         "hbm_ceiling_measured_GBps": dict(ceiling, spec=HBM_PEAK_GBPS, note="1-GiB device-to-device copy and stream triad on this box, untimed section; `peak` in the rooflines stays the 8 TB/s spec"),
         "config": {"workload": wl["name"], "gaussians": wl["P"], "resolution": [wl["W"], wl["H"]],
                    "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step" + ("; + bucketed gradient all-reduce (--dp-grads)" if a.dp_grads else ""),

@@ -57,9 +57,76 @@ __global__ void __launch_bounds__(256) image_stats_kernel(const float *__restric
     }
 }
 
+// Sustained rate of v_mfma_f32_32x32x16_bf16 on random operands, two waves per SIMD on every SIMD, operands in registers (the MLP
+// kernels' instruction; no memory traffic at all): what the chip holds under the matrix load at its power limit -- the clock
+// drops from 2.4 to ~1.6 GHz (MI355X_MICROARCH.md, DVFS give-back), so the dense-peak figure of 2.5 PFLOP/s is not a sustained
+// rate.  bench.py states this number beside the spec peak its roofline uses.
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) mfma_ceiling_kernel(const uint32_t *__restrict__ seed,
+                                                                                                       float *__restrict__ out, int iters)
+{
+    uint32_t r[16];
+    const uint32_t s0 = seed[threadIdx.x & 63] ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { uint32_t x = s0 + 0x9E3779B9u * (uint32_t)(i + 1); x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; r[i] = (x & 0x3FFF3FFFu) | 0x3C003C00u; }   // bf16 pairs in [0.0078, 2)
+    bf16x8c a[2], b[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
+        a[q] = __builtin_bit_cast(bf16x8c, u32x4c{r[8 * q], r[8 * q + 1], r[8 * q + 2], r[8 * q + 3]});
+        b[q] = __builtin_bit_cast(bf16x8c, u32x4c{r[8 * q + 4], r[8 * q + 5], r[8 * q + 6], r[8 * q + 7]});
+    }
+    f32x16c acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {   // 32 dependent-chain-free MFMAs per iteration on two accumulators
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 1], b[(u >> 1) & 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(u >> 1) & 1], b[u & 1], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) { acc0[i] *= 0.5f; acc1[i] *= 0.25f; }   // keep the sums finite; 32 VALU per 32 MFMAs
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += acc0[i] + acc1[i];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 }  // namespace ed3
 
 using namespace ed3;
+
+extern "C" int ed3dgs_measure_mfma_ceiling(int iters, double *tflops, double *ms_out)
+{
+    if (iters <= 0 || !tflops) { set_error("ed3dgs_measure_mfma_ceiling: bad arguments"); return ED3DGS_ERR_INVALID; }
+    const int blocks = 512;   // 2 blocks of 4 waves per CU: two waves per SIMD
+    uint32_t *seed = nullptr; float *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = check_hip(hipMalloc((void **)&seed, 64 * sizeof(uint32_t)), "ceiling seed") && check_hip(hipMalloc((void **)&out, (size_t)blocks * 256 * sizeof(float)), "ceiling out");
+    uint32_t hs[64];
+    for (int i = 0; i < 64; i++) hs[i] = 0x12345u * (uint32_t)(i + 7) + 0x9E3779B9u;
+    ok = ok && check_hip(hipMemcpy(seed, hs, sizeof hs, hipMemcpyHostToDevice), "ceiling seed copy") && check_hip(hipEventCreate(&e0), "event") && check_hip(hipEventCreate(&e1), "event");
+    float ms = 0.f;
+    if (ok) {
+        hipLaunchKernelGGL(mfma_ceiling_kernel, dim3(blocks), dim3(256), 0, nullptr, seed, out, iters / 8 + 1);   // warm-up: clocks settle
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(mfma_ceiling_kernel, dim3(blocks), dim3(256), 0, nullptr, seed, out, iters);
+        (void)hipEventRecord(e1, nullptr);
+        ok = check_hip(hipEventSynchronize(e1), "ceiling sync") && check_hip(hipEventElapsedTime(&ms, e0, e1), "ceiling time");
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (seed) (void)hipFree(seed);
+    if (out) (void)hipFree(out);
+    if (!ok) return ED3DGS_ERR_HIP;
+    const double flops = (double)blocks * 4.0 * (double)iters * 32.0 * 32768.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    if (ms_out) *ms_out = ms;
+    return 0;
+}
 
 extern "C" int ed3dgs_image_stats(const float *image, const float *weight, size_t n, float mid, float *acc, float *out3, void *stream)
 {

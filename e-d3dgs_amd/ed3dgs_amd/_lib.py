@@ -54,7 +54,8 @@ def lib():
     for n in ("ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible", "ed3dgs_state_view_get",
               "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
               "ed3dgs_activations_backward", "ed3dgs_compute_3d_filter", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts",
-              "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts"):
+              "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts",
+              "ed3dgs_measure_mfma_ceiling"):
         getattr(L, n).restype = C.c_int
     L.ed3dgs_set_option.argtypes = [C.c_char_p, C.c_int]
     L.ed3dgs_get_option.argtypes = [C.c_char_p]
@@ -70,7 +71,7 @@ EXPORTS = (
     "ed3dgs_activations_backward", "ed3dgs_filter3d_workspace_bytes", "ed3dgs_compute_3d_filter",
     "ed3dgs_knn_workspace_bytes", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours",
     "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts",
-    "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts")
+    "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts", "ed3dgs_measure_mfma_ceiling")
 
 
 def set_option(name, value):

@@ -142,6 +142,11 @@ int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geome
  * `acc` = 3 floats of device scratch, zero before the first call; every call leaves them zero.  16-byte aligned inputs. */
 int ed3dgs_image_stats(const float *image, const float *weight, size_t n, float mid, float *acc, float *out3, void *stream);
 
+/* Measurement aid (bench.py): the bf16 MFMA rate the chip SUSTAINS -- v_mfma_f32_32x32x16_bf16 back to back on random operands in
+ * registers, two waves per SIMD on every SIMD, `iters` x 32 MFMAs per wave, default stream, synchronous.  tflops = executed flops /
+ * hipEvent time: about two thirds of the 2.5 PFLOP/s dense peak (the clock drops under the matrix load).  Not part of the data path. */
+int ed3dgs_measure_mfma_ceiling(int iters, double *tflops, double *ms);
+
 /* Activations between the deformation network and the rasterizer (gaussian_renderer/__init__.py:77-83;
  * scene/gaussian_model.py:37-45 and, with filter_3D != NULL, :594-603): rot = normalize(rot_raw), scales = exp(s) or
  * sqrt(exp(s)^2 + f^2), opacity = sigmoid(o) [* sqrt(prod exp(s)^2 / prod(exp(s)^2 + f^2))].  Inputs/outputs [P,3],

@@ -268,6 +268,27 @@ def test_autograd_function_and_module_surface():
                                rs.tanfovy, 0.0, 192, 256, shs.detach(), 3, rs.campos, False, False, True, False)
 
 
+def test_unproduced_planes_are_read_only_zeros_and_stay_zero():
+    """the planes a variant does not produce (FFF: coord, mcoord, depth, mdepth, normal) are one cached zero expanded
+    to the shape -- they read as zeros, stay zeros after later calls of OTHER variants (the library is handed NULL for them,
+    never the shared 4 bytes), and an in-place write raises instead of aliasing every later plane."""
+    _need_gpu()
+    inp = util.scene_inputs(2000, 160, 128, scene_seed=33)
+    out_f, _ = util.hip_forward_raw(inp, "FFF")
+    planes = [out_f[2], out_f[3], out_f[6], out_f[7], out_f[8]]      # coord, mcoord, normal, depth, mdepth
+    for t in planes:
+        assert float(t.abs().max()) == 0.0 and t.shape[-2:] == (128, 160)
+    out_t, _ = util.hip_forward_raw(inp, "TTT")                    # a variant that WRITES those planes (its own tensors)
+    assert float(out_t[7].abs().max()) > 0 and float(out_t[6].abs().max()) > 0
+    from ed3dgs_amd import synthetic as S
+    grads = S.make_upstream_grads(128, 160, seed=5)
+    util.hip_backward_raw(inp, out_f, util.zero_unused_grads(grads, "FFF"), "FFF")   # and a backward of the plain variant
+    for t in planes:
+        assert float(t.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        planes[3].add_(1.0)
+
+
 def test_empty_and_culled_inputs():
     """P = 0 short-circuits to zero images; every Gaussian behind the camera renders the background only."""
     _need_gpu()
