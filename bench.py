@@ -445,6 +445,14 @@ def main():
             step(item_at(k), backward=False, coord=True)
         torch.cuda.synchronize()
         dt_r = time.perf_counter() - t1
+        # ... and the deformation forward WITHOUT kept activations (inference), timed in a short pass of its own: what keeping costs
+        L.ed3dgs_profile_begin_slots(ctypes.c_int(12), ctypes.c_uint(1 << 2))
+        for k in range(min(8, a.steps)):
+            step(item_at(k), backward=False, coord=True)
+        torch.cuda.synchronize()
+        nk_ms, nk_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
+        L.ed3dgs_profile_end_slots(nk_ms, nk_n)
+        fwd_nokeep_ms = nk_ms[2] / max(nk_n[2], 1)
     dt_r = D.max_over_ranks(dt_r, device)
 
     # ---- extras, not the headline: the same K steps / K renders with the deformation MLP in its other two modes ----
@@ -556,11 +564,12 @@ def main():
                            "TFLOPs_fp32_equivalent": tfl(mac, tab_avg[sl], rows),
                            "matrix_pipe": "bf16 (%d exact piece products per multiply)" % pr if pr > 1 else "f32"}
         kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
-    # K7 against the vector-ALU roof: its inner loop issues K7_VALU_PER_ITER vector instructions per visited (tile, Gaussian)
-    # iteration (counted in the ISA of render_backward_kernel<false,true>: 211 at 4 issue cycles + 8 transcendentals at 8), a
-    # SIMD issues one per cycle, 1024 SIMDs at 2.4 GHz; iterations and blended pairs are COUNTED by the kernel in the
-    # instrumented pass (popcount of the valid masks), the time is that pass's launch time with the counting on
-    K7_ISSUE_CYCLES_PER_ITER = 211 * 4 + 8 * 8
+    # K7 against the vector-ALU roof: its inner loop issues this many vector instructions per visited iteration (an iteration
+    # now differentiates up to four Gaussians, one per quadrant; counted in the ISA of render_backward_kernel<false,true>,
+    # tools/isa.sh, round 3: 64 + 189 at 4 issue cycles, 4 v_exp_f32 + 4 v_rcp_f32 at 8), a SIMD issues one per cycle, 1024 SIMDs
+    # at 2.4 GHz; iterations and blended pairs are COUNTED by the kernel in the instrumented pass (popcount of the valid
+    # masks), the time is that pass's launch time with the counting on
+    K7_ISSUE_CYCLES_PER_ITER = (64 + 189) * 4 + 8 * 8
     it_per_s = k7_work[0] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0   # counts are per item (deterministic); time = the instrumented pass's launches
     valu_roof = {"visited_iterations_per_launch": k7_work[0], "blended_pairs_per_launch": k7_work[1],
                  "list_entries_staged_per_launch": k7_work[2], "entries_kept_by_tile_reject_per_launch": k7_work[3],
@@ -572,14 +581,15 @@ def main():
                          "counts from a separate pass over the first %d items (counting slows K7 to %.3f ms per launch; that is not the time used)" % (n_count, k7_count_ms)}
     valu_roof["quadrant_entries_queued_per_launch"] = k7_work[4]   # (entry, quadrant) pairs the four quadrants' sub-lists hold
     valu_roof["quadrant_entries_per_iteration"] = k7_work[4] / k7_work[0] if k7_work[0] else 0.0   # of 4 slots
-    # K6 against the same roof (ISA of render_forward_kernel<false,true>, tools/isa.sh: a list entry kept by the tile-level reject
-    # costs 44 four-cycle vector instructions + 4 v_exp_f32 for the per-pixel tests; one that blends anything, 86 more)
-    K6_TEST_CYCLES, K6_BLEND_CYCLES = 44 * 4 + 4 * 8, 86 * 4
-    k6_cycles = k6_work[3] * K6_TEST_CYCLES + k6_work[0] * K6_BLEND_CYCLES
+    # K6 against the same roof (ISA of render_forward_kernel<false,true>, tools/isa.sh, round 3: the per-pixel tests of an iteration
+    # -- up to four Gaussians, one per quadrant -- cost 62 four-cycle vector instructions + 4 v_exp_f32, the blend 98 more;
+    # iterations in which nothing blends pay the tests only and are not counted: a lower bound of the cycles needed)
+    K6_TEST_CYCLES, K6_BLEND_CYCLES = 62 * 4 + 4 * 8, 98 * 4
+    k6_cycles = k6_work[0] * (K6_TEST_CYCLES + K6_BLEND_CYCLES)
     valu_roof_k6 = {"visited_iterations_per_launch": k6_work[0], "blended_pairs_per_launch": k6_work[1],
                     "list_entries_staged_per_launch": k6_work[2], "entries_kept_by_tile_reject_per_launch": k6_work[3],
                     "pairs_per_iteration": k6_work[1] / k6_work[0] if k6_work[0] else 0.0,
-                    "issue_cycles_per_kept_entry": K6_TEST_CYCLES, "extra_issue_cycles_per_visited_iteration": K6_BLEND_CYCLES,
+                    "issue_cycles_per_visited_iteration": K6_TEST_CYCLES + K6_BLEND_CYCLES,
                     "issue_cycles_per_launch": k6_cycles,
                     "frac": k6_cycles / (k6_ms * 1e-3 * 1024 * 2.4e9) if k6_ms > 0 else 0.0,
                     "pairs_per_s": k6_work[1] / (k6_ms * 1e-3) if k6_ms > 0 else 0.0,
@@ -636,6 +646,13 @@ def main():
                    "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
         "render_fps": world * a.steps / dt_r,
         "render_fps_note": "forward only, all outputs (coord+depth+normal), torch.no_grad, incl. deformation",
+        "deform_kept_activations": {
+            "forward_keeping_ms": tab_avg[2], "forward_not_keeping_ms": fwd_nokeep_ms, "cost_of_keeping_ms": tab_avg[2] - fwd_nokeep_ms,
+            "kept_bytes_per_launch": 2 * 6 * 128 * 4 * wl["P"] if wl.get("deform", True) else 0,
+            "rows_read_back": (mean(active_rows) if active_rows else None),
+            "note": "the training forward writes relu(hid) and relu(z_k) of every Gaussian (6 x 128 floats per stage) for the weight-gradient "
+                    "kernels, which read the ACTIVE rows only; re-forming z_k for the active rows instead is five of the forward's six 128-wide "
+                    "products over rows_read_back rows (DESIGN.md section 9)"},
         "deform_backward_rows": {"active_mean": (mean(active_rows) if active_rows else None), "of": wl["P"],
                                  "walked": rows_bwd,
                                  "note": "Gaussians with a non-zero upstream gradient in the counted items (the rest are culled or "
