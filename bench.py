@@ -378,12 +378,12 @@ def main():
     _C.LAST.clear()
 
     # ---- per-kernel table: an instrumented, UNTIMED pass (five event pairs per step cost stream time) ----
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0xFF))
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0x1FF))
     for k in range(a.steps):
         step(item_at(k))
     step.drain()
     torch.cuda.synchronize()
-    NS = 8  # ED3DGS_PROF_SLOTS; slot 4 is the three weight-gradient launches together, 5..7 each of them
+    NS = 9  # ED3DGS_PROF_SLOTS; slot 4 is the three weight-gradient launches together, 5..7 each of them, 8 = K8+K9
     tab_ms, tab_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
     L.ed3dgs_profile_end_slots(tab_ms, tab_n)
     tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(NS)]
@@ -556,6 +556,7 @@ def main():
         "_mode": mode,
         "render_forward_kernel<false,true> (K6)": {"avg_launch_ms": tab_avg[0], "launches": tab_n[0], "bound": "valu", "GBps_algorithmic": bytes_k6 / (tab_avg[0] * 1e-3) / 1e9 if tab_avg[0] > 0 else 0.0},
         "render_backward_kernel<false,true> (K7)": {"avg_launch_ms": tab_avg[1], "launches": tab_n[1], "bound": "valu", "GBps_algorithmic": bytes_k7 / (tab_avg[1] * 1e-3) / 1e9 if tab_avg[1] > 0 else 0.0},
+        "preprocess_backward_kernel (K8+K9)": {"avg_launch_ms": tab_avg[8], "launches": tab_n[8], "bound": "latency"},
     }
     if dm:
         for sl, (nm, mac, pr) in K.items():

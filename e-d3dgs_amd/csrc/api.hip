@@ -55,6 +55,7 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     obtain(chunk, g.rec_coord, P * RECC, 128);
     obtain(chunk, g.depths, P, 128);
     obtain(chunk, g.cov3D, P * 6, 128);
+    obtain(chunk, g.eig, P * 16, 128);
     obtain(chunk, g.clamped, P, 128);
     obtain(chunk, g.tiles_touched, P, 128);
     g.scan_size = scan_temp_bytes((int)P);
@@ -390,10 +391,12 @@ int ed3dgs_rasterize_backward(
         if (pb) prof_stop(ED3DGS_PROF_TILE_BACKWARD, s);
         if (!ok("render backward")) return ED3DGS_ERR_HIP;
     }
+    const bool pg = prof_start(ED3DGS_PROF_GAUSSIAN_BACKWARD, s);
     launch_preprocess_backward(P, D, M, means3D, radii, shs, scales, rotations, scale_modifier, cov3D_precomp,
                                viewmatrix, projmatrix, cam_pos, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, geom,
                                grec, grec_coord, colors_precomp != nullptr, q1_reference != 0, width, height,
                                dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, s);
+    if (pg) prof_stop(ED3DGS_PROF_GAUSSIAN_BACKWARD, s);
     if (!ok("preprocess backward")) return ED3DGS_ERR_HIP;
     return 0;
 }

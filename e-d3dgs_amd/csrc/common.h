@@ -48,6 +48,7 @@ struct GeometryState {
     float *rec_coord;      // [P][12]
     float *depths;         // [P]
     float *cov3D;          // [P][6]
+    float *eig;            // [P][16] K1's eigen-decomposition of cov3D {values[3], converged, vectors[9]}: K8 rereads it (EIG_REC)
     uint8_t *clamped;      // [P]
     uint32_t *tiles_touched;
     uint32_t *point_offsets;   // inclusive scan of tiles_touched in Gaussian order: formed on demand (ed3dgs_state_view_get) only

@@ -78,7 +78,7 @@ struct Cov2DOut { float cov[3]; float cam_plane[6]; float normal[3]; float ray_p
 template <bool INTE = false>
 __device__ inline bool cov2d_planes(v3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
                                     float kernel_size, const float *cov3D, const float *__restrict__ view, Cov2DOut &o,
-                                    float *inv6 = nullptr)
+                                    float *inv6 = nullptr, float *__restrict__ eig_out = nullptr)
 {
     v3 t = xform4x3(mean, view);
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
@@ -106,6 +106,13 @@ __device__ inline bool cov2d_planes(v3 mean, float focal_x, float focal_y, float
 
     m3 evec; float eval[3];
     int Dn = eig_sym3(Vrk, eval, evec);
+    if (eig_out) {   // kept for the backward: K8 needs the same decomposition, and the iterative solver was 14 of its 63 us
+        float4 *e4 = reinterpret_cast<float4 *>(eig_out);
+        e4[0] = make_float4(eval[0], eval[1], eval[2], (float)Dn);
+        e4[1] = make_float4(evec.m[0][0], evec.m[0][1], evec.m[0][2], evec.m[1][0]);
+        e4[2] = make_float4(evec.m[1][1], evec.m[1][2], evec.m[2][0], evec.m[2][1]);
+        eig_out[12] = evec.m[2][2];
+    }
     unsigned min_id = eval[0] > eval[1] ? (eval[1] > eval[2] ? 2 : 1) : (eval[0] > eval[2] ? 2 : 0);
     m3 Vrk_inv;
     bool well_conditioned = eval[min_id] > 0.00000001;
@@ -195,14 +202,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
     uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition,
-    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax)
+    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax, float *__restrict__ eig)
 {
     const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = idx_raw < P;
     const int idx = live ? idx_raw : P - 1;
     // (Tried in round 2: the block's SH rows fetched as one coalesced stream into LDS and read from there -- 53 us instead of
-    // 41 us at 200k: 50 KB of LDS per block halves the resident waves, and this kernel lives on latency hiding, not on the
-    // load instructions' efficiency.)
+    // 41 us at 200k: 50 KB of LDS per block halves the resident waves.  Tried in round 3: the row into registers as twelve
+    // 16-byte loads issued before the covariance chain -- 44.3 against 43.5 us: three waves per SIMD of ~5 000 vector
+    // instructions each (the iterative eigen-solver most of them) is what this kernel takes; it does not wait on memory.)
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t out_key = 0xFFFFFFFFu;  // culled Gaussians sort to the end of the depth order (they emit nothing)
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
 #pragma unroll
             for (int i = 0; i < 6; i++) invraycov[6 * (size_t)idx + i] = inv6[i];   // zeros where the reference leaves its zero fill
         } else {
-            cov2d_planes<false>(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, c2);
+            cov2d_planes<false>(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, view, c2, nullptr, eig ? eig + (size_t)idx * 16 : nullptr);
         }
         float ts = sqrtf(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
         float cx = c2.cov[0], cy = c2.cov[1], cz = c2.cov[2];
@@ -981,13 +989,14 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition,
-                           g.block_tiles, g.block_kminmax);
-    else
+                           g.block_tiles, g.block_kminmax, (float *)nullptr);
+    else {
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, (float *)nullptr,
-                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax);
+                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax, g.eig);
+    }
 }
 
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s)

@@ -6,6 +6,10 @@
 #include "common.h"
 #include "devmath.h"
 
+#ifndef ED3_K89_ABLATE
+#define ED3_K89_ABLATE 0   // timing experiments (tools/ab_build.sh; results wrong): 1 no phase 2, 2 no dead-row SH stream, 4 no SH backward, 8 no live-row SH copy-out
+#endif
+
 namespace ed3 {
 
 __device__ const float BSH_C0 = 0.28209479177387814f;
@@ -27,9 +31,10 @@ __device__ __forceinline__ v3 dnormvdv3(v3 v, v3 dv)
     return r;
 }
 
-// returns dL/dmean contribution; writes dL_dsh[0..M)
-__device__ inline v3 sh_backward(int deg, int M, v3 pos, v3 campos, const float *__restrict__ s, uint8_t clamped,
-                                 v3 dL_dRGB, float *__restrict__ out)
+// returns dL/dmean contribution; writes dL_dsh[0..M) -- IN PLACE over the coefficients: `row` holds the Gaussian's 3 M SH
+// coefficients on entry (gathered into the caller's LDS row by the whole block, coalesced) and dL/dsh on return, so every
+// coefficient is read (the direction derivatives) before anything is written (CR/backward.cu:24-147)
+__device__ inline v3 sh_backward(int deg, int M, v3 pos, v3 campos, float *row, uint8_t clamped, v3 dL_dRGB)
 {
     v3 dir_orig = pos - campos;
     v3 dir = dir_orig / len3(dir_orig);
@@ -37,29 +42,16 @@ __device__ inline v3 sh_backward(int deg, int M, v3 pos, v3 campos, const float 
     dL_dRGB.y *= (clamped & 2) ? 0.f : 1.f;
     dL_dRGB.z *= (clamped & 4) ? 0.f : 1.f;
     v3 dx = mk3(0, 0, 0), dy = mk3(0, 0, 0), dz = mk3(0, 0, 0);
-    float x = dir.x, y = dir.y, z = dir.z;
-#define SH(k) mk3(s[3 * (k)], s[3 * (k) + 1], s[3 * (k) + 2])
-#define SETSH(k, f) do { v3 q__ = dL_dRGB * (f); out[3 * (k)] = q__.x; out[3 * (k) + 1] = q__.y; out[3 * (k) + 2] = q__.z; } while (0)
-    SETSH(0, BSH_C0);
-    int written = 1;
+    const float x = dir.x, y = dir.y, z = dir.z;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#define SH(k) mk3(row[3 * (k)], row[3 * (k) + 1], row[3 * (k) + 2])
     if (deg > 0) {
-        SETSH(1, -BSH_C1 * y); SETSH(2, BSH_C1 * z); SETSH(3, -BSH_C1 * x);
-        written = 4;
         dx = SH(3) * (-BSH_C1); dy = SH(1) * (-BSH_C1); dz = SH(2) * BSH_C1;
         if (deg > 1) {
-            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            SETSH(4, BSH_C2[0] * xy); SETSH(5, BSH_C2[1] * yz); SETSH(6, BSH_C2[2] * (2.f * zz - xx - yy));
-            SETSH(7, BSH_C2[3] * xz); SETSH(8, BSH_C2[4] * (xx - yy));
-            written = 9;
             dx = dx + (SH(4) * (BSH_C2[0] * y) + SH(6) * (BSH_C2[2] * 2.f * -x) + SH(7) * (BSH_C2[3] * z) + SH(8) * (BSH_C2[4] * 2.f * x));
             dy = dy + (SH(4) * (BSH_C2[0] * x) + SH(5) * (BSH_C2[1] * z) + SH(6) * (BSH_C2[2] * 2.f * -y) + SH(8) * (BSH_C2[4] * 2.f * -y));
             dz = dz + (SH(5) * (BSH_C2[1] * y) + SH(6) * (BSH_C2[2] * 2.f * 2.f * z) + SH(7) * (BSH_C2[3] * x));
             if (deg > 2) {
-                SETSH(9, BSH_C3[0] * y * (3.f * xx - yy)); SETSH(10, BSH_C3[1] * xy * z);
-                SETSH(11, BSH_C3[2] * y * (4.f * zz - xx - yy)); SETSH(12, BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                SETSH(13, BSH_C3[4] * x * (4.f * zz - xx - yy)); SETSH(14, BSH_C3[5] * z * (xx - yy));
-                SETSH(15, BSH_C3[6] * x * (xx - 3.f * yy));
-                written = 16;
                 dx = dx + (SH(9) * (BSH_C3[0] * 3.f * 2.f * xy) + SH(10) * (BSH_C3[1] * yz) + SH(11) * (BSH_C3[2] * -2.f * xy) +
                            SH(12) * (BSH_C3[3] * -3.f * 2.f * xz) + SH(13) * (BSH_C3[4] * (-3.f * xx + 4.f * zz - yy)) +
                            SH(14) * (BSH_C3[5] * 2.f * xz) + SH(15) * (BSH_C3[6] * 3.f * (xx - yy)));
@@ -73,8 +65,28 @@ __device__ inline v3 sh_backward(int deg, int M, v3 pos, v3 campos, const float 
         }
     }
 #undef SH
+    // (`row` is not restrict-qualified: the stores below stay behind the loads above)
+#define SETSH(k, f) do { v3 q__ = dL_dRGB * (f); row[3 * (k)] = q__.x; row[3 * (k) + 1] = q__.y; row[3 * (k) + 2] = q__.z; } while (0)
+    SETSH(0, BSH_C0);
+    int written = 1;
+    if (deg > 0) {
+        SETSH(1, -BSH_C1 * y); SETSH(2, BSH_C1 * z); SETSH(3, -BSH_C1 * x);
+        written = 4;
+        if (deg > 1) {
+            SETSH(4, BSH_C2[0] * xy); SETSH(5, BSH_C2[1] * yz); SETSH(6, BSH_C2[2] * (2.f * zz - xx - yy));
+            SETSH(7, BSH_C2[3] * xz); SETSH(8, BSH_C2[4] * (xx - yy));
+            written = 9;
+            if (deg > 2) {
+                SETSH(9, BSH_C3[0] * y * (3.f * xx - yy)); SETSH(10, BSH_C3[1] * xy * z);
+                SETSH(11, BSH_C3[2] * y * (4.f * zz - xx - yy)); SETSH(12, BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                SETSH(13, BSH_C3[4] * x * (4.f * zz - xx - yy)); SETSH(14, BSH_C3[5] * z * (xx - yy));
+                SETSH(15, BSH_C3[6] * x * (xx - 3.f * yy));
+                written = 16;
+            }
+        }
+    }
 #undef SETSH
-    for (int k = written; k < M; k++) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
+    for (int k = written; k < M; k++) { row[3 * k] = 0.f; row[3 * k + 1] = 0.f; row[3 * k + 2] = 0.f; }
     v3 dL_ddir = mk3(dot3(dx, dL_dRGB), dot3(dy, dL_dRGB), dot3(dz, dL_dRGB));
     return dnormvdv3(dir_orig, dL_ddir);
 }
@@ -106,53 +118,72 @@ __device__ inline void cov3d_backward(v3 scale, float mod, float4 rot, const flo
 #undef MT
 }
 
-// one Gaussian; the SH gradient row (3 M floats) goes to sh_row -- an LDS row of the caller, written out coalesced
+// every output of one Gaussian as zero (culled, or its record untouched by the tile pass); sh_row / dL_dscale may be null
+__device__ __forceinline__ void write_zero_outputs(int idx, int M, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dcolor,
+                                                   float *__restrict__ dL_dopacity, float *__restrict__ dL_dmean3D,
+                                                   float *__restrict__ dL_dcov3D, float *__restrict__ sh_row,
+                                                   float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) { dL_dmean2D[3 * idx + i] = 0.f; dL_dcolor[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
+    dL_dopacity[idx] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
+    if (sh_row) for (int i = 0; i < 3 * M; i++) sh_row[i] = 0.f;
+    if (dL_dscale) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) dL_dscale[3 * idx + i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
+    }
+}
+
+// one live Gaussian; sh_row: its SH coefficients on entry, dL/dsh on return (an LDS row of the caller, gathered / written out coalesced)
 __device__ __forceinline__ void preprocess_backward_body(
     int idx, int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     const float *__restrict__ cov3D_precomp, const float *__restrict__ view, const float *__restrict__ proj,
     const float *__restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, float kernel_size,
-    const float *__restrict__ rec, const float *__restrict__ cov3Ds, const uint8_t *__restrict__ clamped,
+    const float *__restrict__ rec, const float *__restrict__ cov3Ds, const float *__restrict__ eig, const uint8_t *__restrict__ clamped,
     const float *__restrict__ grec, const float *__restrict__ grec_coord, bool has_colors_precomp, bool q1_reference,
     float hW, float hH, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dcolor, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D, float *__restrict__ sh_row,
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
-    auto write_zeros = [&]() {
-#pragma unroll
-        for (int i = 0; i < 3; i++) { dL_dmean2D[3 * idx + i] = 0.f; dL_dcolor[3 * idx + i] = 0.f; dL_dmean3D[3 * idx + i] = 0.f; }
-        dL_dopacity[idx] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
-        if (shs) for (int i = 0; i < 3 * M; i++) sh_row[i] = 0.f;
-        if (scales) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) dL_dscale[3 * idx + i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
-        }
-    };
-    if (!(radii[idx] > 0)) { write_zeros(); return; }
-    // ---- unpack the tile pass' record, apply the per-Gaussian linear post-factors ----
+    // Only LIVE Gaussians get here (radius > 0 and a record the tile pass added to: phase 1 of the kernel).  Everything the
+    // chain below reads is requested here, before any of it is used (the reference reads each input at its first use, several
+    // behind branches: a dozen memory latencies in a row where one will do).
     float gr[GREC];
     {
         const float4 *g4 = reinterpret_cast<const float4 *>(grec + (size_t)idx * GREC);
 #pragma unroll
         for (int i = 0; i < 4; i++) { float4 t = g4[i]; gr[4 * i] = t.x; gr[4 * i + 1] = t.y; gr[4 * i + 2] = t.z; gr[4 * i + 3] = t.w; }
     }
-    {   // A record the tile pass never added to (the Gaussian is behind the last contributor of every tile it touches: half of a
-        // dense scene): every output is a sum of products with a factor from the record -- exactly zero.  Written as such
-        // without reading the Gaussian's other 400 bytes.
-        bool untouched = true;
+    float gcv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (grec_coord) {
+        const float *gc = grec_coord + (size_t)idx * GREC;
 #pragma unroll
-        for (int i = 0; i < GREC; i++) untouched &= gr[i] == 0.f;
-        if (untouched && grec_coord) {
-            const float *gc = grec_coord + (size_t)idx * GREC;
-#pragma unroll
-            for (int i = 0; i < 9; i++) untouched &= gc[i] == 0.f;
-        }
-        if (untouched) { write_zeros(); return; }
+        for (int i = 0; i < 9; i++) gcv[i] = gc[i];
     }
+    float cov3D[6];
+    {
+        const float *src = cov3D_precomp ? cov3D_precomp + 6 * idx : cov3Ds + 6 * idx;
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3D[i] = src[i];
+    }
+    const v3 mean = mk3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
+    const float rec_w = rec[(size_t)idx * REC + R_W];
+    const float4 *e4 = reinterpret_cast<const float4 *>(eig + (size_t)idx * 16);
+    const float4 eg0 = e4[0], eg1 = e4[1], eg2 = e4[2];
+    const float eg3 = eig[(size_t)idx * 16 + 12];
+    const uint8_t clamp_bits = clamped[idx];
+    v3 sc_in = mk3(0, 0, 0);
+    float4 rot_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scales) {
+        sc_in = mk3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        rot_in = reinterpret_cast<const float4 *>(rotations)[idx];
+    }
+    // ---- unpack the tile pass' record, apply the per-Gaussian linear post-factors ----
     const v3 g_color = mk3(gr[G_R], gr[G_G], gr[G_B]);
     const float dL_dt = gr[G_TS];
     const float drx = gr[G_RPX] / h_x, dry = gr[G_RPY] / h_y;
@@ -163,22 +194,14 @@ __device__ __forceinline__ void preprocess_backward_body(
     v3 gv = mk3(0, 0, 0);
     float cp0x = 0, cp0y = 0, cp1x = 0, cp1y = 0, cp2x = 0, cp2y = 0;
     if (grec_coord) {
-        const float *gc = grec_coord + (size_t)idx * GREC;
-        gv = mk3(gc[0], gc[1], gc[2]);
-        cp0x = gc[3] / h_x; cp0y = gc[4] / h_y; cp1x = gc[5] / h_x; cp1y = gc[6] / h_y; cp2x = gc[7] / h_x; cp2y = gc[8] / h_y;
+        gv = mk3(gcv[0], gcv[1], gcv[2]);
+        cp0x = gcv[3] / h_x; cp0y = gcv[4] / h_y; cp1x = gcv[5] / h_x; cp1y = gcv[6] / h_y; cp2x = gcv[7] / h_x; cp2y = gcv[8] / h_y;
     }
     dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = g2z;
     dL_dcolor[3 * idx] = g_color.x; dL_dcolor[3 * idx + 1] = g_color.y; dL_dcolor[3 * idx + 2] = g_color.z;
 
     // ---- K8: conic / planes / normal -> cov3D, mean ----
-    float cov3D[6];
-    {
-        const float *src = cov3D_precomp ? cov3D_precomp + 6 * idx : cov3Ds + 6 * idx;
-#pragma unroll
-        for (int i = 0; i < 6; i++) cov3D[i] = src[i];
-    }
-    const v3 mean = mk3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
-    const float combined_opacity = q1_reference ? dLc_z : rec[(size_t)idx * REC + R_W];  // Q1
+    const float combined_opacity = q1_reference ? dLc_z : rec_w;  // Q1
     v3 t = xform4x3(mean, view);
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
     float txtz = t.x / t.z, tytz = t.y / t.z;
@@ -199,7 +222,11 @@ __device__ __forceinline__ void preprocess_backward_body(
     const float coef = (float)sqrt(det_0 / (det_1 + 1e-6) + 1e-6);
 
     m3 evec; float eval[3];
-    int Dn = eig_sym3(Vrk, eval, evec);
+    // the forward's decomposition of the same matrix (K1 kept it: the iterative solver -- CR/auxiliary.h:217-401, which the
+    // reference's backward runs again -- was 14 of this kernel's 63 us)
+    const int Dn = (int)eg0.w;
+    eval[0] = eg0.x; eval[1] = eg0.y; eval[2] = eg0.z;
+    evec = cols3(eg1.x, eg1.y, eg1.z, eg1.w, eg2.x, eg2.y, eg2.z, eg2.w, eg3);
     unsigned min_id = eval[0] > eval[1] ? (eval[1] > eval[2] ? 2 : 1) : (eval[0] > eval[2] ? 2 : 0);
     m3 Vrk_inv; v3 emin = mk3(0, 0, 0);
     const float eval_min = min_id == 0 ? eval[0] : (min_id == 1 ? eval[1] : eval[2]);
@@ -364,52 +391,143 @@ __device__ __forceinline__ void preprocess_backward_body(
     float tl = sqrtf(mv.x * mv.x + mv.y * mv.y + mv.z * mv.z);
     v3 d2 = xformvec4x3T(mk3(gv.x + mv.x / tl * dL_dt, gv.y + mv.y / tl * dL_dt, gv.z + mv.z / tl * dL_dt), view);
     dmean = dmean + mk3(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z);
-    if (shs && !has_colors_precomp) {
-        v3 ds = sh_backward(D, M, mean, mk3(campos[0], campos[1], campos[2]), shs + (size_t)idx * M * 3, clamped[idx],
-                            g_color, sh_row);
+    if (shs && !has_colors_precomp && !(ED3_K89_ABLATE & 4)) {
+        v3 ds = sh_backward(D, M, mean, mk3(campos[0], campos[1], campos[2]), sh_row, clamp_bits, g_color);
         dmean = dmean + ds;
     }
     dL_dmean3D[3 * idx] = dmean.x; dL_dmean3D[3 * idx + 1] = dmean.y; dL_dmean3D[3 * idx + 2] = dmean.z;
     if (scales) {
-        v3 sc = mk3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-        float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
-        cov3d_backward(sc, scale_modifier, q, dcov, dL_dscale + 3 * idx, dL_drot + 4 * idx);
+        cov3d_backward(sc_in, scale_modifier, rot_in, dcov, dL_dscale + 3 * idx, dL_drot + 4 * idx);
     }
 }
 
-// thread = Gaussian.  dL_dsh is the largest output (192 B per Gaussian at degree 3); written per thread it is 48
-// stores of 4 bytes at a 192-byte lane stride.  The rows are staged in LDS (odd row stride: conflict-free) and the
-// block writes its 256 rows -- contiguous in memory -- as one coalesced stream.
-// (Round 3: 153 registers = 3 waves per SIMD, and the 50 KB of SH staging per block allow 3 blocks per CU = the same 3 waves:
-// asking the allocator for 4 / 5 waves (128 / 96 registers) spills and LOSES: 63 -> 72 / 91 us at 200k.)
+// Block = KB_ROWS consecutive Gaussians, in two phases.  Half of a dense scene is culled or behind the last contributor of every
+// tile it touches (an all-zero record, all-zero outputs), and with thread = Gaussian nearly every wave held a few live lanes
+// and ran the whole chain for them (63 us at 200k, ~44 % live).  Phase 1: every thread classifies KB_ROWS / 256 Gaussians from
+// radii and the tile pass' record alone, writes the zero outputs of the dead ones, and the block compacts the live ids into
+// an LDS list (ballot + one LDS atomic per wave).  Phase 2: dense waves walk the list -- a wave with no entry leaves at once.
+// dL_dsh is the largest output (192 B per Gaussian at degree 3); written per thread it is 48 stores of 4 bytes at a 192-byte
+// lane stride.  The live rows are staged in LDS (odd row stride: conflict-free) and written out row by row, coalesced within
+// a row; the dead rows are zeroed by the whole block as one stream with holes.
+// (153 registers = 3 waves per SIMD; asking the allocator for 4 / 5 waves spills and loses, round 3.)
+constexpr int KB_ROWS = 512;
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     const float *__restrict__ cov3D_precomp, const float *__restrict__ view, const float *__restrict__ proj,
     const float *__restrict__ campos, float h_x, float h_y, float tan_fovx, float tan_fovy, float kernel_size,
-    const float *__restrict__ rec, const float *__restrict__ cov3Ds, const uint8_t *__restrict__ clamped,
+    const float *__restrict__ rec, const float *__restrict__ cov3Ds, const float *__restrict__ eig, const uint8_t *__restrict__ clamped,
     const float *__restrict__ grec, const float *__restrict__ grec_coord, bool has_colors_precomp, bool q1_reference,
     float hW, float hH, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dcolor, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
     extern __shared__ float sh_rows[];
+    __shared__ int live_list[KB_ROWS];
+    __shared__ uint8_t live_flag[KB_ROWS];
+    __shared__ int n_live;
     const int w3 = 3 * M, ld = w3 | 1;                // odd stride
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int first = blockIdx.x * KB_ROWS, nrow = min(KB_ROWS, P - first);
     const bool staged = shs && !has_colors_precomp;   // the case in which every Gaussian's SH row is written
-    float *row = staged ? sh_rows + threadIdx.x * ld : (dL_dsh ? dL_dsh + (size_t)min(idx, P - 1) * w3 : nullptr);
-    if (idx < P)
-        preprocess_backward_body(idx, P, D, M, means, radii, shs, scales, rotations, scale_modifier, cov3D_precomp, view, proj,
-                                 campos, h_x, h_y, tan_fovx, tan_fovy, kernel_size, rec, cov3Ds, clamped, grec, grec_coord,
-                                 has_colors_precomp, q1_reference, hW, hH, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D,
-                                 dL_dcov3D, row, dL_dscale, dL_drot);
-    if (!staged) return;
+    if (tid == 0) n_live = 0;
     __syncthreads();
-    const int first = blockIdx.x * blockDim.x, nrow = min((int)blockDim.x, P - first);
-    float *out = dL_dsh + (size_t)first * w3;
-    for (int e = threadIdx.x; e < nrow * w3; e += blockDim.x) {
-        const int r = e / w3, cc = e - r * w3;
-        out[e] = sh_rows[r * ld + cc];
+    // ---- phase 1: classify, zero the dead Gaussians' small outputs, compact the live ids ----
+#pragma unroll
+    for (int k = 0; k < KB_ROWS / 256; k++) {
+        const int i = k * 256 + tid, idx = first + i;
+        bool live = false;
+        if (i < nrow) {
+            live = radii[idx] > 0;
+            if (live) {
+                const float4 *g4 = reinterpret_cast<const float4 *>(grec + (size_t)idx * GREC);
+                bool untouched = true;
+#pragma unroll
+                for (int q = 0; q < GREC / 4; q++) { const float4 t = g4[q]; untouched &= t.x == 0.f && t.y == 0.f && t.z == 0.f && t.w == 0.f; }
+                if (untouched && grec_coord) {
+                    const float *gc = grec_coord + (size_t)idx * GREC;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) untouched &= gc[q] == 0.f;
+                }
+                live = !untouched;
+            }
+            if (!live)
+                write_zero_outputs(idx, M, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D,
+                                   (shs && !staged && dL_dsh) ? dL_dsh + (size_t)idx * w3 : nullptr, scales ? dL_dscale : nullptr, dL_drot);
+            live_flag[i] = live;
+        }
+        const unsigned long long m = __ballot(live);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&n_live, __popcll(m));
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (live) live_list[wbase + __popcll(m & ((1ull << lane) - 1))] = idx;
+    }
+    __syncthreads();
+    const int n = n_live;
+    // ---- dead rows of dL_dsh: one coalesced stream with holes (under way while phase 2 computes) ----
+    if (staged && n < nrow && !(ED3_K89_ABLATE & 2)) {
+        float *out = dL_dsh + (size_t)first * w3;
+        if ((w3 & 3) == 0) {
+            const int q4 = w3 >> 2;
+            for (int e = tid; e < nrow * q4; e += 256)
+                if (!live_flag[e / q4]) reinterpret_cast<float4 *>(out)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int e = tid; e < nrow * w3; e += 256)
+                if (!live_flag[e / w3]) out[e] = 0.f;
+        }
+    }
+    // ---- phase 2: the live Gaussians, 256 at a time ----
+    for (int r0 = 0; r0 < ((ED3_K89_ABLATE & 1) ? 0 : n); r0 += 256) {
+        const int slot = r0 + tid, cnt = min(256, n - r0);
+        const int q4 = w3 >> 2, tot4 = cnt * q4;
+        if (staged) {
+            // the live rows' SH coefficients into the LDS rows: 16-byte chunks, consecutive lanes along a row (one row per thread
+            // read where it is used is 3 M loads at a 12 M-byte lane stride)
+            if ((w3 & 3) == 0) {
+                for (int e0 = tid; e0 < tot4; e0 += 1024) {
+                    float4 v[4];
+                    int dst[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int e = min(e0 + 256 * u, tot4 - 1), r = e / q4, c4 = e - r * q4;
+                        v[u] = reinterpret_cast<const float4 *>(shs + (size_t)live_list[r0 + r] * w3)[c4];
+                        dst[u] = r * ld + 4 * c4;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (e0 + 256 * u < tot4) { float *d = sh_rows + dst[u]; d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w; }
+                }
+            } else {
+                for (int e = tid; e < cnt * w3; e += 256) {
+                    const int r = e / w3, cc = e - r * w3;
+                    sh_rows[r * ld + cc] = shs[(size_t)live_list[r0 + r] * w3 + cc];
+                }
+            }
+            __syncthreads();
+        }
+        if (slot < n) {
+            const int idx = live_list[slot];
+            preprocess_backward_body(idx, P, D, M, means, radii, shs, scales, rotations, scale_modifier, cov3D_precomp, view, proj,
+                                     campos, h_x, h_y, tan_fovx, tan_fovy, kernel_size, rec, cov3Ds, eig, clamped, grec, grec_coord,
+                                     has_colors_precomp, q1_reference, hW, hH, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D,
+                                     dL_dcov3D, staged ? sh_rows + tid * ld : nullptr, dL_dscale, dL_drot);
+        }
+        if (!staged) continue;
+        __syncthreads();
+        if (ED3_K89_ABLATE & 8) continue;
+        if ((w3 & 3) == 0) {
+            for (int e = tid; e < tot4; e += 256) {
+                const int r = e / q4, c4 = e - r * q4;
+                const float *sr = sh_rows + r * ld + 4 * c4;
+                reinterpret_cast<float4 *>(dL_dsh + (size_t)live_list[r0 + r] * w3)[c4] = make_float4(sr[0], sr[1], sr[2], sr[3]);
+            }
+        } else {
+            for (int e = tid; e < cnt * w3; e += 256) {
+                const int r = e / w3, cc = e - r * w3;
+                dL_dsh[(size_t)live_list[r0 + r] * w3 + cc] = sh_rows[r * ld + cc];
+            }
+        }
+        if (r0 + 256 < n) __syncthreads();
     }
 }
 
@@ -423,9 +541,9 @@ void launch_preprocess_backward(int P, int D, int M, const float *means, const i
                                 float *dL_dscale, float *dL_drot, hipStream_t s)
 {
     const size_t lds = (shs && !colors_precomp) ? (size_t)256 * ((3 * M) | 1) * sizeof(float) : 0;   // SH gradient rows
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + 255) / 256), dim3(256), lds, s, P, D, M, means, radii, shs,
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + KB_ROWS - 1) / KB_ROWS), dim3(256), lds, s, P, D, M, means, radii, shs,
                        scales, rotations, scale_modifier, cov3D_precomp, view, proj, campos, focal_x, focal_y, tan_fovx,
-                       tan_fovy, kernel_size, g.rec, g.cov3D, g.clamped, grec, grec_coord, colors_precomp, q1_reference,
+                       tan_fovy, kernel_size, g.rec, g.cov3D, g.eig, g.clamped, grec, grec_coord, colors_precomp, q1_reference,
                        0.5f * W, 0.5f * H, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                        dL_drot);
 }

@@ -110,8 +110,13 @@ __device__ __forceinline__ void row_transpose_reduce(float (&v)[NV], int lane, f
     }
 }
 
+// waves per SIMD asked of the allocator for the headline instantiation (0 = its own choice: 140 registers, 3 waves).  Round 3:
+// 4 waves (128 registers, 52 B of scratch per lane) measured 0.460 against 0.438 ms (tools/ab_build.sh k7w4 -DED3_K7_WAVES=4).
+#ifndef ED3_K7_WAVES
+#define ED3_K7_WAVES 0
+#endif
 template <bool COORD, bool DEPTH>
-__global__ void __launch_bounds__(64) render_backward_kernel(
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COORD && DEPTH && ED3_K7_WAVES) ? ED3_K7_WAVES : 1), ((!COORD && DEPTH && ED3_K7_WAVES) ? ED3_K7_WAVES : 8)))) render_backward_kernel(
     int W, int H, int gx, const uint32_t *__restrict__ tile_order, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, const float4 *__restrict__ rec_coord, float focal_x, float focal_y,
     const float *__restrict__ bg, const float *__restrict__ alphas, const float *__restrict__ normalmap,

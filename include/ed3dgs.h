@@ -238,7 +238,8 @@ enum {
     ED3DGS_PROF_DEFORM_WGRAD_TRUNK = 5,  /* ... of which: deform_wgrad_kernel (dW1 / db1) */
     ED3DGS_PROF_DEFORM_WGRAD_WIDE = 6,   /* ... the wide (SH) head's launch(es) */
     ED3DGS_PROF_DEFORM_WGRAD_NARROW = 7, /* ... the narrow heads' launch */
-    ED3DGS_PROF_SLOTS = 8,
+    ED3DGS_PROF_GAUSSIAN_BACKWARD = 8,   /* K8+K9 preprocess_backward_kernel */
+    ED3DGS_PROF_SLOTS = 9,
     ED3DGS_PROF_COUNTERS = 16,      /* length of the tile kernels' work-counter array (ed3dgs_profile_tile_counts) */
     ED3DGS_PROF_COUNT_WORK = 1 << 30   /* flag in the slot mask: also count K7's work (ed3dgs_profile_tile_backward_counts) */
 };

@@ -6,7 +6,7 @@ show() { python - <<PY
 import json
 d=json.load(open("$1")); k=d["kernels"]
 g=lambda n: round([v for kk,v in k.items() if kk.startswith(n)][0]["avg_launch_ms"],4)
-print("%-12s step %.4f med %.4f | fwd %.4f dgrad %.4f wg_narrow %.4f wg_wide %.4f K6 %.4f K7 %.4f | fps %d" % ("$2", d["ms_per_step"], d["step_ms"]["median"], g("deform_forward"), g("deform_dgrad"), g("deform_head_wgrad_tr_kernel<false>"), g("deform_head_wgrad_tr_kernel<true>"), g("render_forward"), g("render_backward"), d["render_fps"]))
+print("%-12s step %.4f med %.4f | fwd %.4f dgrad %.4f wg_narrow %.4f wg_wide %.4f K6 %.4f K7 %.4f K89 %.4f | fps %d" % ("$2", d["ms_per_step"], d["step_ms"]["median"], g("deform_forward"), g("deform_dgrad"), g("deform_head_wgrad_tr_kernel<false>"), g("deform_head_wgrad_tr_kernel<true>"), g("render_forward"), g("render_backward"), g("preprocess_backward"), d["render_fps"]))
 PY
 }
 for rep in 1 2; do
