@@ -166,33 +166,57 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     const size_t T = tiles_of(width, height);
     img = ImageState::from_chunk(img_chunk, (size_t)width * height, T);
 
-    launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
-                      colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
-                      focal_y, kernel_size, radii, geom, s, invraycov, condition);
-    if (!ok("preprocess")) return ED3DGS_ERR_HIP;
     // The one read-back of the path (CR/rasterizer_impl.cu:359: the instance count sizes the binning buffers).  The reference
-    // scans tiles_touched for it; nothing here needs the per-Gaussian offsets (the level-2 transpose scans per tile), so the
-    // preprocess blocks leave their sums (4 bytes per 256 Gaussians) and the host adds them up -- no scan launches.  The copy
-    // goes to pinned memory and is followed by an event; the work that does not need the count -- binning level 1
-    // (binning.hip: Gaussians by depth) -- is enqueued BEHIND the copy, and the host waits for the event only.  By the time
-    // the GPU has finished the level-1 sort the host has allocated the binning buffers and enqueued the rest, so the stream
-    // never runs dry (the reference's cudaMemcpy drains it).
+    // scans tiles_touched and copies the last element; here the preprocess blocks add their sums up with one atomic each and the
+    // last of them stores the total straight into host-coherent memory (CountMail, common.h): no copy and no event on the
+    // stream -- each of those is a barrier packet, ~10 us of idle stream per frame together -- and the work that does not need
+    // the count (binning level 1: the Gaussians by depth) is enqueued right behind K1.  The host polls the word for this
+    // call's sequence number; by the time the GPU has finished the level-1 sort the host has allocated the binning buffers
+    // and enqueued the rest, so the stream never runs dry (the reference's cudaMemcpy drains it).
+    // ED3DGS_COUNT_COPY=1: the round-2 form (per-block sums copied to pinned memory, an event, the host adds them up).
     static thread_local struct Readback {
-        uint32_t *host = nullptr;
+        uint32_t *host = nullptr;            // COUNT_COPY: pinned copy of block_tiles
         size_t cap = 0;
         hipEvent_t ev = nullptr;
+        unsigned long long *word = nullptr;  // host-coherent mail word
+        unsigned long long *counter = nullptr;
+        int dev = -1;
+        unsigned seq = 0;
     } rb;
     const size_t nblk = ((size_t)P + 255) / 256;
-    if (rb.cap < nblk) {
-        if (rb.host) (void)hipHostFree(rb.host);
-        rb.host = nullptr; rb.cap = 0;
-        const size_t cap = std::max<size_t>(4096, nblk * 2);
-        if (!check_hip(hipHostMalloc((void **)&rb.host, cap * sizeof(uint32_t), hipHostMallocDefault), "pinned read-back buffer")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
-        rb.cap = cap;
+    const bool by_copy = opt(OPT_COUNT_COPY) != 0;
+    CountMail mail = {nullptr, nullptr, 0u};
+    if (!by_copy) {
+        int dev = 0;
+        if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return ED3DGS_ERR_HIP;
+        if (rb.dev != dev) {   // first call of this thread on this device (buffers of another device are left to it: a few bytes)
+            rb.word = nullptr; rb.counter = nullptr;
+            if (!check_hip(hipHostMalloc((void **)&rb.word, 64, hipHostMallocCoherent | hipHostMallocMapped), "count mail word") ||
+                !check_hip(hipMalloc((void **)&rb.counter, 64), "count mail counter") ||
+                !check_hip(hipMemset(rb.counter, 0, 64), "count mail counter")) return ED3DGS_ERR_HIP;
+            *rb.word = 0ull;
+            rb.dev = dev;
+        }
+        rb.seq = (rb.seq + 1u) & 0xFFFFFFu;
+        if (rb.seq == 0u) rb.seq = 1u;
+        mail.counter = rb.counter; mail.host_word = rb.word; mail.seq = rb.seq;
     }
-    if (!rb.ev && !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipMemcpyAsync(rb.host, geom.block_tiles, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
+    launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
+                      colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
+                      focal_y, kernel_size, radii, geom, s, invraycov, condition, mail);
+    if (!ok("preprocess")) return ED3DGS_ERR_HIP;
+    if (by_copy) {
+        if (rb.cap < nblk) {
+            if (rb.host) (void)hipHostFree(rb.host);
+            rb.host = nullptr; rb.cap = 0;
+            const size_t cap = std::max<size_t>(4096, nblk * 2);
+            if (!check_hip(hipHostMalloc((void **)&rb.host, cap * sizeof(uint32_t), hipHostMallocDefault), "pinned read-back buffer")) { rb.host = nullptr; return ED3DGS_ERR_HIP; }
+            rb.cap = cap;
+        }
+        if (!rb.ev && !check_hip(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming), "read-back event")) return ED3DGS_ERR_HIP;
+        if (!check_hip(hipMemcpyAsync(rb.host, geom.block_tiles, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
+        if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
+    }
     // binning level 1: the Gaussians by depth.  The library's sort (rocPRIM merge sort below a million keys: 9 launches, 60-70 us
     // at 200k) stays the default: the hand-written three-pass radix sort (binning.hip, ED3DGS_SORT_HANDWRITTEN=1) is bit-identical
     // and takes 6 launches but 80 us -- measured in round 3
@@ -206,9 +230,30 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
         if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
     }
     if (!ok("depth order")) return ED3DGS_ERR_HIP;
-    if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
     uint64_t num_rendered_u = 0;
-    for (size_t b = 0; b < nblk; b++) num_rendered_u += rb.host[b];
+    if (by_copy) {
+        if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
+        for (size_t b = 0; b < nblk; b++) num_rendered_u += rb.host[b];
+    } else {
+        // poll the mail word; every so often ask the stream whether it has failed or (stream idle, word still old) the store
+        // is lost, so that a faulted launch ends in an error and not in a spin
+        const volatile unsigned long long *w = rb.word;
+        unsigned long long v = *w;
+        for (unsigned long long spins = 0; (v >> 40) != (unsigned long long)mail.seq; spins++) {
+            if ((spins & 0xFFFFu) == 0xFFFFu) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) { check_hip(q, "waiting for the instance count"); return ED3DGS_ERR_HIP; }
+                if (q == hipSuccess) {
+                    v = *w;
+                    if ((v >> 40) != (unsigned long long)mail.seq) { set_error("the preprocess launch finished without delivering the instance count"); return ED3DGS_ERR_HIP; }
+                    break;
+                }
+            }
+            __builtin_ia32_pause();
+            v = *w;
+        }
+        num_rendered_u = v & ((1ull << 40) - 1ull);
+    }
     if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
     const int R = (int)num_rendered_u;
 

@@ -25,7 +25,7 @@ enum { G_R = 0, G_G, G_B, G_TS, G_RPX, G_RPY, G_NX, G_NY, G_NZ, G_MX, G_MY, G_MZ
 // (ED3DGS_<name>=<int>; any non-numeric non-empty value counts as 1), and changed afterwards only through
 // ed3dgs_set_option() -- no entry point reads the environment per call.
 #define ED3_OPTIONS(X) \
-    X(BIN_ONE_LEVEL) X(BIN_RADIX) X(BIN_TIMING) X(SORT_HANDWRITTEN) \
+    X(BIN_ONE_LEVEL) X(BIN_RADIX) X(BIN_TIMING) X(COUNT_COPY) X(SORT_HANDWRITTEN) \
     X(DEFORM_BF16X3) X(DEFORM_DENSE_BWD) X(DEFORM_FP32_MFMA) X(DEFORM_NO_TAIL) X(FB_ABLATE) X(FWD_TIMING) \
     X(PREP_SEQ) X(STATS_BLOCKS) X(WG_ABLATE) X(WG_TIMING)
 enum Opt {
@@ -96,12 +96,20 @@ inline void obtain(char *&chunk, T *&ptr, size_t count, size_t alignment = 128)
 }
 
 // ---- launchers (one per kernel file) ----
+// K1's instance count, handed to the host without a copy: every preprocess block adds its sum (and a ticket, in the high bits) to
+// `counter` with one 64-bit atomic; the block that takes the last ticket stores {seq, total} to `host_word` -- host memory the
+// device writes through (hipHostMallocCoherent) -- and re-arms the counter.  The host polls the word for its seq (api.hip).
+struct CountMail {
+    unsigned long long *counter;     // device, zero between launches
+    unsigned long long *host_word;   // host-coherent: (seq << 40) | total
+    unsigned seq;                    // 24 bits
+};
 void launch_preprocess(int P, int D, int M, const float *means, const float *scales, float scale_modifier,
                        const float *rotations, const float *opacities, const float *tongue, const float *shs,
                        const float *cov3D_precomp, const float *colors_precomp, const float *view, const float *proj,
                        const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
                        float kernel_size, int *radii, GeometryState g, hipStream_t s, float *invraycov = nullptr,
-                       uint8_t *condition = nullptr);
+                       uint8_t *condition = nullptr, CountMail mail = CountMail{nullptr, nullptr, 0u});
 void launch_mark_visible(int P, const float *means, const float *view, uint8_t *present, hipStream_t s);
 void launch_duplicate_with_keys(int P, const GeometryState &g, const int *radii, int W, int H, uint32_t *tile_keys,
                                 uint32_t *values, hipStream_t s);

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
     uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition,
-    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax, float *__restrict__ eig)
+    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax, float *__restrict__ eig, CountMail mail)
 {
     const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = idx_raw < P;
@@ -302,6 +302,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         block_tiles[blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
         block_kminmax[2 * blockIdx.x] = min(min(wave_kmin[0], wave_kmin[1]), min(wave_kmin[2], wave_kmin[3]));
         block_kminmax[2 * blockIdx.x + 1] = max(max(wave_kmax[0], wave_kmax[1]), max(wave_kmax[2], wave_kmax[3]));
+        if (mail.counter) {   // the count goes to the host from here: no copy, no event on the stream (see CountMail)
+            const unsigned long long mine = (unsigned long long)(wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3]) | (1ull << 40);
+            const unsigned long long old = atomicAdd(mail.counter, mine);
+            if ((old >> 40) == gridDim.x - 1) {
+                atomicExch(mail.counter, 0ull);
+                const unsigned long long total = (old + mine) & ((1ull << 40) - 1ull);
+                __hip_atomic_store(mail.host_word, ((unsigned long long)mail.seq << 40) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -981,7 +990,7 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                        const float *rotations, const float *opacities, const float *tongue, const float *shs,
                        const float *cov3D_precomp, const float *colors_precomp, const float *view, const float *proj,
                        const float *campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-                       float kernel_size, int *radii, GeometryState g, hipStream_t s, float *invraycov, uint8_t *condition)
+                       float kernel_size, int *radii, GeometryState g, hipStream_t s, float *invraycov, uint8_t *condition, CountMail mail)
 {
     int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     if (invraycov)   // the integrate path's variant (CR/forward.cu:875-945 with integrate = true)
@@ -989,13 +998,13 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition,
-                           g.block_tiles, g.block_kminmax, (float *)nullptr);
+                           g.block_tiles, g.block_kminmax, (float *)nullptr, mail);
     else {
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, (float *)nullptr,
-                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax, g.eig);
+                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax, g.eig, mail);
     }
 }
 

@@ -95,3 +95,18 @@ def test_other_binning_paths_agree(switch, path, libopt):
     _need_gpu()
     libopt(switch, 1)
     _lists_equal(_giants(util.scene_inputs(20000, 1100, 1604, scene_seed=19, cam_seed=20), 10, 30.0), path)
+
+
+@pytest.mark.parametrize("case", ["giants-1080p", "one-row", "1025-rows", "wide-radix"])
+def test_count_by_copy_agrees(case, libopt):
+    """The instance count reaches the host through a host-coherent word K1's last block writes (csrc/common.h, CountMail);
+    ED3DGS_COUNT_COPY=1 is the round-2 form (per-block sums copied to pinned memory behind an event).  Same count, same lists --
+    and the default form again afterwards (its sequence number and counter survive a call of the other form)."""
+    _need_gpu()
+    ref = _lists_equal(*CASES[case]())
+    libopt("COUNT_COPY", 1)
+    got = _lists_equal(*CASES[case]())
+    assert got["num_rendered"] == ref["num_rendered"]
+    libopt("COUNT_COPY", 0)
+    again = _lists_equal(*CASES[case]())
+    assert again["num_rendered"] == ref["num_rendered"]
