@@ -64,6 +64,9 @@ CASES = [
     ("w32_nofine_noc2f", 32, 1, 5, 25, 17, 3000, 2, 0.25, 5, 5, dict(no_fine_deform=True, no_c2f_temporal_embedding=True, no_do=False)),
     ("w32_reflect_time", 32, 1, 5, 25, 9, 12000, 0, 1.2, 5, 5, dict(no_do=False, temporal_embedding_dim=64)),
     ("w32_it0_zero_temporal", 32, 1, 5, 25, 9, 0, None, 0.6, 5, 5, dict(zero_temporal=True)),
+    # the layer-by-layer path of the HIP side (csrc/deform_deep.hip): width 256, and a 64-wide Gaussian embedding at width 128
+    ("w256_d1_it4000", 256, 1, 5, 25, 29, 4000, 2, 0.63, 6, 7, dict(no_do=False)),
+    ("w128_e64_d2", 128, 2, 5, 25, 23, 9000, None, 0.15, 8, 5, dict(no_do=False, gaussian_embedding_dim=64, temporal_embedding_dim=128)),
 ]
 
 
