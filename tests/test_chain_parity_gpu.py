@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import util
-from test_raster_parity_gpu import MARGIN, TOL_IMG, _check_images, _check_state
+from test_raster_parity_gpu import MARGIN, TOL_GRAD, TOL_IMG, _check_images, _check_state
 
 pytestmark = pytest.mark.gpu
 TOL_CHAIN = 1e-4
@@ -121,10 +121,11 @@ def test_render_parameter_gradients_vs_oracle_chain(variant):
         assert v <= TOL_CHAIN, (k, v)
 
 
-def test_c5_item_500k_all_outputs_forward():
+def test_c5_item_500k_all_outputs_forward_and_backward():
     """BASELINE.json configs[4], one item: 500k Gaussians, SH degree 3, 1080p, full deformation, depth / coord / normal outputs
     (TTT): deformation vs the golden-pinned numpy restatement, rasterizer on the HIP deformation's own outputs vs the OpenMP
-    C oracle on those same numbers -- tile lists, ranges, keys bit-exact, images 1e-4 -- and render() equal to the raw call."""
+    C oracle on those same numbers -- tile lists, ranges, keys bit-exact, images 1e-4 --, render() equal to the raw call, and the
+    backward kernels (every plane's gradient in) against the oracle's backward at kernel level."""
     _need_gpu()
     from ed3dgs_amd import synthetic as S
     from ed3dgs_amd.activations import fused_activations
@@ -166,3 +167,13 @@ def test_c5_item_500k_all_outputs_forward():
     for k, i in (("render", 1), ("expected_coord", 2), ("median_coord", 3), ("mask", 4), ("normal", 6), ("expected_depth", 7),
                  ("median_depth", 8), ("radii", 9)):
         assert torch.equal(pkg[k].detach(), out[i]), k
+    # backward at the same size, kernel level (K7 + K8 + K9 with every output plane's gradient): the C oracle's backward fed the
+    # HIP forward's saved state, upstream gradients zeroed on the threshold-marginal pixels
+    grads = util.zero_unused_grads(S.make_upstream_grads(H, W), "TTT")
+    grads, _ = util.mask_marginal(grads, fw, MARGIN)
+    bw = util.oracle_backward(inp, util.oracle_state_from_hip(fw, out, sv), grads, "TTT")
+    got = util.hip_backward_raw(inp, out, grads, "TTT")
+    gerr = {n: util.grad_err(got[n].reshape(bw[n].shape), bw[n]) for n in util.GRAD_NAMES}
+    print("C5 item bwd (kernel level)", gerr)
+    for n, v in gerr.items():
+        assert v <= TOL_GRAD, (n, v)
