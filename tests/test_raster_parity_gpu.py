@@ -25,7 +25,8 @@ pytestmark = pytest.mark.gpu
 
 TOL_IMG = 1e-4
 TOL_GRAD = 5e-5      # backward kernels alone: oracle backward fed with the HIP forward's saved state
-TOL_GRAD_E2E = 2e-3  # forward+backward end to end (see test_backward_parity_c1 docstring)
+TOL_GRAD_E2E = 5e-4  # forward+backward end to end (see test_backward_parity_c1 docstring); measured <= 1.8e-4 since the tile
+                     # kernels evaluate alpha in the reference's operation order (round 3; 2e-3 / 3e-4 before)
 MARGIN = util.MARGIN    # 1e-6 on the alpha threshold, x5 on the transmittance thresholds (util.MARGIN_WEIGHTS)
 MAX_MASKED_FRAC = 3e-4  # printed per test
 
