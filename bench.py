@@ -218,6 +218,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-points", action="store_true", help="also time the CPU restatement at C1 (in full) and at the C2 point (SURVEY 8d); minutes of CPU work")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed extra passes in the MLP's other multiply modes (for profiles)")
+    ap.add_argument("--train-only", action="store_true", help="skip the forward-only render-fps passes too, so that every launch of the run is a "
+                    "training-step launch (for rocprofv3 --stats: its per-kernel averages then are the training step's)")
     ap.add_argument("--dp-grads", action="store_true", help="also all-reduce the gradients every step (data-parallel training; not the headline configuration)")
     ap.add_argument("--rehearse-launcher", action="store_true",
                     help="NO GPU work and NO measurement: run the launcher / rendezvous / sharding / collectives / JSON plumbing "
@@ -369,9 +371,10 @@ def main():
     torch.cuda.synchronize()
     log("warm-up done; bookkeeping pass")
     reff, npairs_ub, rsum = [], [], []
-    with torch.no_grad():
+    import contextlib
+    with (contextlib.nullcontext() if a.train_only else torch.no_grad()):   # (--train-only: full steps here too, no inference launch in the run)
         for k in range(a.steps):
-            step(item_at(k), backward=False)
+            step(item_at(k), backward=a.train_only)
             r, n, R = r_eff_of_last(wl)
             reff.append(r); npairs_ub.append(n); rsum.append(R)
     _C.KEEP_LAST = False
@@ -388,7 +391,7 @@ def main():
     L.ed3dgs_profile_end_slots(tab_ms, tab_n)
     tab_avg = [tab_ms[i] / max(tab_n[i], 1) for i in range(NS)]
     # K7's work counts (visited iterations, blended pairs, ...): a short pass of its own -- counting slows the kernel down
-    n_count = min(4, a.steps)
+    n_count = 0 if a.train_only else min(4, a.steps)   # (--train-only: no counting launches either -- they are slower ones)
     L.ed3dgs_profile_begin_slots(ctypes.c_int(n_count + 2), ctypes.c_uint(3 | (1 << 30)))
     # ... and the rows the deformation backward walks: Gaussians with a non-zero upstream gradient = non-zero dL/d embedding rows
     active_rows = []
@@ -443,26 +446,28 @@ def main():
     log("timed region done: %.3f ms/step" % (dt / a.steps * 1e3))
     # ---- forward-only render fps (render.py's TTT variant), untimed w.r.t. the headline ----
     torch.cuda.synchronize()
-    with torch.no_grad():
-        t1 = time.perf_counter()
-        for k in range(a.steps):
-            step(item_at(k), backward=False, coord=True)
-        torch.cuda.synchronize()
-        dt_r = time.perf_counter() - t1
-        # ... and the deformation forward WITHOUT kept activations (inference), timed in a short pass of its own: what keeping costs
-        L.ed3dgs_profile_begin_slots(ctypes.c_int(12), ctypes.c_uint(1 << 2))
-        for k in range(min(8, a.steps)):
-            step(item_at(k), backward=False, coord=True)
-        torch.cuda.synchronize()
-        nk_ms, nk_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
-        L.ed3dgs_profile_end_slots(nk_ms, nk_n)
-        fwd_nokeep_ms = nk_ms[2] / max(nk_n[2], 1)
+    dt_r, fwd_nokeep_ms = float("inf"), None
+    if not a.train_only:
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            for k in range(a.steps):
+                step(item_at(k), backward=False, coord=True)
+            torch.cuda.synchronize()
+            dt_r = time.perf_counter() - t1
+            # ... and the deformation forward WITHOUT kept activations (inference), timed in a short pass of its own: what keeping costs
+            L.ed3dgs_profile_begin_slots(ctypes.c_int(12), ctypes.c_uint(1 << 2))
+            for k in range(min(8, a.steps)):
+                step(item_at(k), backward=False, coord=True)
+            torch.cuda.synchronize()
+            nk_ms, nk_n = (ctypes.c_double * NS)(), (ctypes.c_int * NS)()
+            L.ed3dgs_profile_end_slots(nk_ms, nk_n)
+            fwd_nokeep_ms = nk_ms[2] / max(nk_n[2], 1)
     dt_r = D.max_over_ranks(dt_r, device)
 
     # ---- extras, not the headline: the same K steps / K renders with the deformation MLP in its other two modes ----
     def other_mode(var, note):
         # not on a multi-rank run (the extra passes carry barriers of their own and are not part of the scaling measurement)
-        if a.no_other_modes or world > 1 or not wl["deform"] or any(_lib.get_option(v) for v in MODE_OPTS):
+        if a.no_other_modes or a.train_only or world > 1 or not wl["deform"] or any(_lib.get_option(v) for v in MODE_OPTS):
             return None
         _lib.set_option(var, 1)
         try:
@@ -649,10 +654,10 @@ def main():
         "config": {"workload": wl["name"], "gaussians": wl["P"], "resolution": [wl["W"], wl["H"]],
                    "items": n_items, "parallelism": f"frames sharded i = rank mod {world}; 12-byte loss all-reduce/step" + ("; + bucketed gradient all-reduce (--dp-grads)" if a.dp_grads else ""),
                    "mean_num_rendered": mean(rsum), "mean_R_eff": mean(reff), "mean_sum_last_contributor": mean(npairs_ub)},
-        "render_fps": world * a.steps / dt_r,
+        "render_fps": None if a.train_only else world * a.steps / dt_r,
         "render_fps_note": "forward only, all outputs (coord+depth+normal), torch.no_grad, incl. deformation",
         "deform_kept_activations": {
-            "forward_keeping_ms": tab_avg[2], "forward_not_keeping_ms": fwd_nokeep_ms, "cost_of_keeping_ms": tab_avg[2] - fwd_nokeep_ms,
+            "forward_keeping_ms": tab_avg[2], "forward_not_keeping_ms": fwd_nokeep_ms, "cost_of_keeping_ms": None if fwd_nokeep_ms is None else tab_avg[2] - fwd_nokeep_ms,
             "kept_bytes_per_launch": 2 * 6 * 128 * 4 * wl["P"] if wl.get("deform", True) else 0,
             "rows_read_back": (mean(active_rows) if active_rows else None),
             "note": "the training forward writes relu(hid) and relu(z_k) of every Gaussian (6 x 128 floats per stage) for the weight-gradient "

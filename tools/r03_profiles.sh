@@ -4,7 +4,7 @@
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-echo "== kernel stats"; tools/prof_bench.sh ${tag}_stats --no-other-modes --steps 40 --warmup 5 > gpurun_out/${tag}_stats.txt 2>&1; tail -3 gpurun_out/${tag}_stats.txt
+echo "== kernel stats (every launch of the run is a training-step launch: --train-only)"; TOPN=40 tools/prof_bench.sh ${tag}_stats --no-other-modes --train-only --steps 40 --warmup 5 > gpurun_out/${tag}_stats.txt 2>&1; tail -3 gpurun_out/${tag}_stats.txt
 echo "== FETCH_SIZE"; tools/pmc_pass.sh ${tag}_fetch FETCH_SIZE > gpurun_out/${tag}_fetch.txt 2>&1
 echo "== WRITE_SIZE"; tools/pmc_pass.sh ${tag}_write WRITE_SIZE > gpurun_out/${tag}_write.txt 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_fetch_write.md gpurun_out/${tag}_pmc_summary.json > /dev/null 2>&1
