@@ -218,6 +218,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-points", action="store_true", help="also time the CPU restatement at C1 (in full) and at the C2 point (SURVEY 8d); minutes of CPU work")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed extra passes in the MLP's other multiply modes (for profiles)")
+    ap.add_argument("--sequential-items", action="store_true", help="rank r's k-th item is its k-th (camera 0, frames 0, 1, ... at N=1): round 2's "
+                    "schedule, for comparisons with its numbers; the default strides over the whole (camera, frame) list")
     ap.add_argument("--train-only", action="store_true", help="skip the forward-only render-fps passes too, so that every launch of the run is a "
                     "training-step launch (for rocprofv3 --stats: its per-kernel averages then are the training step's)")
     ap.add_argument("--dp-grads", action="store_true", help="also all-reduce the gradients every step (data-parallel training; not the headline configuration)")
@@ -351,7 +353,8 @@ def main():
     step = make_step(model, cams, grads, wl, device, dp_grads=a.dp_grads)
     n_items = wl["cams"] * wl["frames"]
     my_items = D.shard_items(max(n_items, world), rank, world)
-    item_at = lambda k: D.strided_item(my_items, k) % n_items   # coprime stride: a 20-step run visits every camera
+    item_at = (lambda k: my_items[k % len(my_items)] % n_items) if a.sequential_items else \
+              (lambda k: D.strided_item(my_items, k) % n_items)   # coprime stride: a 20-step run visits every camera
     ceiling = hbm_ceiling(device) if rank == 0 else None
     mfma_ceiling = None
     if rank == 0:   # what the matrix pipe sustains on this box (untimed): the spec peak the roofline uses is not a sustained rate
