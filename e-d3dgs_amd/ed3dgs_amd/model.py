@@ -79,6 +79,19 @@ class SynthGaussianModel:
     def get_opacity(self):
         return self.opacity_activation(self._opacity)
 
+    def get_covariance(self, scaling_modifier=1):
+        """scene/gaussian_model.py:31-35,143-144: strip_symmetric(L L^T), L = R(q / |q|) diag(modifier * exp(_scaling)) of the
+        UNDEFORMED parameters, as six values per Gaussian in the rasterizer's order (xx, xy, xz, yy, yz, zz)."""
+        s = scaling_modifier * self.get_scaling
+        q = torch.nn.functional.normalize(self._rotation)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)), 1).reshape(-1, 3, 3)
+        L = R * s[:, None, :]
+        c = L @ L.transpose(1, 2)
+        return torch.stack((c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]), 1)
+
     def apply_scaling_n_opacity_with_3D_filter(self, opacity, scales):
         """scene/gaussian_model.py:594-603"""
         opacity = self.opacity_activation(opacity)

@@ -44,6 +44,16 @@ def _settings(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifie
     )
 
 
+def _eval_sh():
+    """The caller's utils.sh_utils.eval_sh when render() runs inside the reference's source tree (:5), else the same
+    polynomials from ed3dgs_amd.sh."""
+    try:
+        from utils.sh_utils import eval_sh
+    except ImportError:
+        from ed3dgs_amd.sh import eval_sh
+    return eval_sh
+
+
 _ZERO_SCALARS = {}
 
 
@@ -76,18 +86,28 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
         shs, shs_rest = pc._features_dc, pc._features_rest
     else:
         shs = pc.get_features
-    scales = rotations = cov3D_precomp = None
-    if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
-    else:
-        scales = pc._scaling
-        rotations = pc._rotation
+    # pipe.compute_cov3D_python (:68-72): the reference hands scales = rotations = None to the deformation network, whose
+    # first line subscripts them (scene/deformation.py:109) -- the branch raises TypeError there.  What the branch is written
+    # to do is kept here instead: the covariance comes from the model's UNDEFORMED scaling / rotation through
+    # pc.get_covariance (scene/gaussian_model.py:143-144), the deformation still moves means, opacity and SH (it is given
+    # the base scaling / rotation it needs; their deformed values are then unused), and the rasterizer gets cov3D_precomp.
+    cov3D_precomp = pc.get_covariance(scaling_modifier) if pipe.compute_cov3D_python else None
+    scales = pc._scaling
+    rotations = pc._rotation
 
+    # viewpoint_camera.time is a Python number; the reference builds a (P,1) tensor of it (:45) of which the network reads
+    # element [0,0] (scene/deformation.py:58) -- a tensor is accepted just the same
     (means3D_final, scales_final, rotations_final, opacity_final, shs_final, extras) = pc._deformation(
         means3D, scales, rotations, opacity, float(viewpoint_camera.time), cam_no, pc, None, shs, iter=iter,
         num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f, sh_coefs_rest=shs_rest)
 
-    if scales_final is not None and _standard_activations(pc) and (disable_filter3D or getattr(pc, "fused_filter3D", False)):
+    if cov3D_precomp is not None:
+        scales_final = rotations_final = None
+        if disable_filter3D:
+            opacity = pc.opacity_activation(opacity_final)
+        else:
+            _, opacity = pc.apply_scaling_n_opacity_with_3D_filter(opacity=opacity_final, scales=pc._scaling)
+    elif _standard_activations(pc) and (disable_filter3D or getattr(pc, "fused_filter3D", False)):
         # one fused launch per direction (csrc/activations.hip) instead of normalize / exp / sigmoid (/ 3D filter)
         scales_final, rotations_final, opacity = fused_activations(
             scales_final, rotations_final, opacity_final, None if disable_filter3D else pc.filter_3D)
@@ -102,7 +122,7 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
     colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            from utils.sh_utils import eval_sh  # only when the caller asks for the Python SH path
+            eval_sh = _eval_sh()
             shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
             dir_pp = pc.get_xyz - viewpoint_camera.camera_center.to(means3D.device).repeat(pc.get_features.shape[0], 1)
             dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
@@ -198,7 +218,7 @@ def integrate(points3D, viewpoint_camera, pc, pipe, bg_color: torch.Tensor, kern
         if override_color is not None:
             colors_precomp, shs = override_color, None
         elif pipe.convert_SHs_python:
-            from utils.sh_utils import eval_sh
+            eval_sh = _eval_sh()
             shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
             dir_pp = pc.get_xyz - viewpoint_camera.camera_center.to(means3D.device).repeat(pc.get_features.shape[0], 1)
             colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True)) + 0.5, 0.0)

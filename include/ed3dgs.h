@@ -222,10 +222,10 @@ int ed3dgs_profile_begin(int max_samples);
  * slot and ED3DGS_PROF_COUNT_WORK on: out4 = {visited (tile, Gaussian) iterations, blended pixel-Gaussian pairs, list entries staged, entries kept by the
  * tile-level reject}.  Measurement only: bench.py prices K7 against the VALU roof with them. */
 int ed3dgs_profile_tile_backward_counts(unsigned long long out4[4]);
-/* All work counters of the tile kernels (first min(n, ED3DGS_PROF_COUNTERS) of them): [0..3] as above (K7); [4..7] K7's visited
- * iterations whose blended pixels lie in 1 / 2 / 3 / 4 of the tile's 8x8 quadrants; [8], [9] sums over K7's visited iterations of
- * the 16x8 (top / bottom) and 8x16 (left / right) tile halves holding a blended pixel; [12..15] K6: visited iterations, blended
- * pairs, list entries staged, entries kept by the tile-level reject. */
+/* All work counters of the tile kernels (first min(n, ED3DGS_PROF_COUNTERS) of them): [0..3] as above (K7); [4] K7's (entry,
+ * quadrant) pairs queued into the quadrants' sub-lists; [5] 64-byte gradient records K7 added to global memory (one per touched
+ * entry and chunk: the count of its global atomics / 16); [12..15] K6: visited iterations, blended pairs, list entries staged,
+ * entries kept by the tile-level reject.  The other slots are unused (zero). */
 int ed3dgs_profile_tile_counts(unsigned long long *out, int n);
 int ed3dgs_profile_end(double *fwd_ms_total, int *fwd_launches, double *bwd_ms_total, int *bwd_launches);
 /* Same, for every timed kernel: arrays of ED3DGS_PROF_SLOTS entries indexed by the slots below. */
@@ -255,7 +255,7 @@ int ed3dgs_profile_end_slots(double *ms_total, int *launches);
  * MFMA with activations resident in registers.  W = net_width (multiple of 32, <= 256), E = gaussian embedding dim
  * (multiple of 32), TD = temporal embedding dim, D = defor_depth (0 or 1: the trunk is one Linear -- every configuration
  * the reference ships; 2..8: (D - 1) further [ReLU, Linear(W, W)] trunk layers, scene/deformation.py:38-44, computed layer by
- * layer by plain fp32 kernels -- exact, not tuned; E must be 32).
+ * layer by plain fp32 kernels -- exact, not tuned; that path also serves W = 256 and any E that is a multiple of 32).
  * Packed parameter block of one stage (fp32, state-dict order of scene/deformation.py:38-51 except that the extra trunk
  * layers come LAST, so that every other offset is independent of D):
  *   feature_out.0.weight[W][TD+E], feature_out.0.bias[W],

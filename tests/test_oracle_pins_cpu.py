@@ -135,8 +135,8 @@ def _torch_run(inp, variant, sigma_inv, g, colors=None, cov=None):
     cov_l = None if cov is None else leaf(cov)
     out = TR.rasterize(inp["bg"].double(), L["means3D"], L["opacities"], L["scales"], L["rotations"], L["shs"],
                        inp["viewmatrix"].double(), inp["projmatrix"].double(), inp["campos"].double(), inp["tanfovx"],
-                       inp["tanfovy"], inp["kernel_size"], H, W, 3, rc, rd, sigma_inv=sigma_inv, cov3D_precomp=cov_l,
-                       colors_precomp=colors_l, extra=extra, keep_pairs=True)
+                       inp["tanfovy"], inp["kernel_size"], H, W, inp["sh_degree"], rc, rd, scale_modifier=inp["scale_modifier"],
+                       sigma_inv=sigma_inv, cov3D_precomp=cov_l, colors_precomp=colors_l, extra=extra, keep_pairs=True)
     loss = sum((out[k] * g[k].double()).sum() for k in ("color", "alpha", "depth", "mdepth", "normal", "coord", "mcoord"))
     loss.backward()
     z = lambda t, like: torch.zeros_like(like) if t.grad is None else t.grad
@@ -178,6 +178,11 @@ def _compare(inp, variant, M, dt, tol_img, tol_grad, colors=None, cov=None, labe
         if n in ("dL_dscales", "dL_drotations") and cov is not None:
             continue
         a, b = tg[n].reshape(bw[n].shape), np.asarray(bw[n], np.float64)
+        if n == "dL_dscales":
+            # quirk Q14: CR/backward.cu:514,540-542 forms s = mod * scale and returns dL/ds as dL_dscale -- the factor
+            # mod = ds/dscale is missing, so the reference's dL_dscales is the true gradient / scale_modifier.  The C
+            # restatement reproduces it; autograd has the true one.
+            b = b * inp["scale_modifier"]
         if n == "dL_dmeans2D":                       # x, y and the abs-grad column compared separately (different scales)
             for nm, sl in (("dL_dmeans2D.xy", slice(0, 2)), ("dL_dmeans2D.z(abs)", slice(2, 3))):
                 gerr[nm] = np.abs(a[:, sl] - b[:, sl]).max() / max(np.abs(b[:, sl]).max(), 1e-300)
@@ -186,6 +191,7 @@ def _compare(inp, variant, M, dt, tol_img, tol_grad, colors=None, cov=None, labe
     print(label, variant, "ks", inp["kernel_size"], "img", {k: "%.1e" % v for k, v in ierr.items()}, "grad", {k: "%.1e" % v for k, v in gerr.items()})
     for n, v in gerr.items():
         assert v <= tol_grad, (label, n, v)
+    return fw, bw, tg
 
 
 # ------------------------------------------------------------------ 2. C oracle vs independent autograd
@@ -199,6 +205,42 @@ def test_c_oracle_vs_autograd_all_outputs_and_gradients(variant, ks):
     # the nearly opaque pixels (T_final < 1e-2: rounding amplified >= 100x) are left out of the loss
     _compare(inp, variant, O, np.float32, 1e-5, 5e-4, label="fp32 build")
     _compare(inp, variant, O, np.float32, 1e-5, 1e-4, label="fp32 build, T_final >= 1e-2", min_T_final=1e-2)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_c_oracle_vs_autograd_lower_sh_degrees(deg):
+    """active_sh_degree 0, 1, 2 with the M = 16 coefficient rows the reference keeps allocated while the degree grows
+    (scene/gaussian_model.py:49,146-148, train.py:129-130; CR/forward.cu:23-74, CR/backward.cu:21-140): colours and every
+    gradient against the independent autograd restatement, and the rows above (deg+1)^2 receive an EXACT zero."""
+    torch.set_num_threads(8)
+    inp = util.scene_inputs(1000, 112, 80, scene_seed=17, sh_degree=deg)
+    fw, bw, tg = _compare(inp, "FTT", O64, np.float64, 1e-7, 1e-6, label="fp64 build, degree %d" % deg)
+    fw, bw, tg = _compare(inp, "FTT", O, np.float32, 1e-5, 5e-4, label="fp32 build, degree %d" % deg)
+    n = (deg + 1) ** 2
+    dsh = np.asarray(bw["dL_dsh"]).reshape(inp["P"], 16, 3)
+    assert np.abs(dsh[:, :n]).max() > 0 and not dsh[:, n:].any()
+    assert not tg["dL_dsh"].reshape(inp["P"], 16, 3)[:, n:].any()
+    if deg == 0:     # no view dependence: the SH path adds nothing to dL_dmeans3D; with higher degrees it does
+        fw3 = _c_forward(O, util.scene_inputs(1000, 112, 80, scene_seed=17, sh_degree=3), "FTT", np.float32)
+        assert np.abs(fw3["rgb"] - fw["rgb"]).max() > 1e-3       # the higher bands are visible in this scene
+
+
+@pytest.mark.parametrize("variant,ks", [("FTT", 0.0), ("TTT", 0.3)])
+def test_c_oracle_vs_autograd_scale_modifier_and_background(variant, ks):
+    """scale_modifier = 0.7 (CR/forward.cu:270-304, CR/backward.cu:492-555: cov3D = (mod S R)^T (mod S R), and the modifier
+    multiplies dL_dscale) and a background that is not white (it enters K7's dL_dalpha, CR/backward.cu:964-969)."""
+    torch.set_num_threads(8)
+    inp = util.scene_inputs(1000, 112, 80, scene_seed=19, kernel_size=ks, scale_modifier=0.7, bg=(0.1, 0.2, 0.3))
+    # fp64 tolerance 3e-6 instead of 1e-6: the reference's hand-derived K8 regularises its quotients (1 / (denom^2 + 1e-7),
+    # det1^2 + 1e-6, coef + 1e-6: CR/backward.cu:367-375,385), autograd differentiates the forward exactly; the two differ by
+    # O(1e-7 / denom^2), which grows as the modifier shrinks the screen-space covariance (6e-8 at modifier 1, 1.5e-6 at 0.7,
+    # 2.7e-5 at 0.5 on this scene, independent of the eigen-solver's threshold)
+    _compare(inp, variant, O64, np.float64, 1e-7, 3e-6, label="fp64 build, mod 0.7, bg")
+    fw, bw, tg = _compare(inp, variant, O, np.float32, 1e-5, 5e-4, label="fp32 build, mod 0.7, bg")
+    fw1 = _c_forward(O, {**inp, "scale_modifier": 1.0}, variant, np.float32)
+    vis = (fw["radii"] > 0) & (fw1["radii"] > 0)
+    want = np.float32(0.7) ** 2 * fw1["cov3D"][vis]
+    assert (np.abs(fw["cov3D"][vis] - want).max(1) <= 1e-6 * np.abs(want).max(1)).all()
 
 
 def test_c_oracle_vs_autograd_precomputed_cov3d_and_colors():

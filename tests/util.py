@@ -9,7 +9,10 @@ from ed3dgs_amd import synthetic as S
 VARIANTS = {"FFF": (False, False), "FTT": (False, True), "TFT": (True, False), "TTT": (True, True)}
 
 
-def scene_inputs(P, W, H, scene_seed=0, cam_seed=1, cam_index=0, n_cams=1, kernel_size=0.0, tongue=False):
+def scene_inputs(P, W, H, scene_seed=0, cam_seed=1, cam_index=0, n_cams=1, kernel_size=0.0, tongue=False, sh_degree=3,
+                 scale_modifier=1.0, bg=(1.0, 1.0, 1.0)):
+    """sh_degree < 3 keeps the M = 16 coefficient rows, as the reference does while active_sh_degree grows
+    (scene/gaussian_model.py:49,146-148, train.py:129-130); the rows above (deg+1)^2 are then present but unused."""
     sc = S.make_scene(P, seed=scene_seed)
     cam = S.make_cameras(n_cams, W, H, seed=cam_seed)[cam_index]
     a = S.activated(sc)
@@ -17,10 +20,10 @@ def scene_inputs(P, W, H, scene_seed=0, cam_seed=1, cam_index=0, n_cams=1, kerne
         g = torch.Generator().manual_seed(7)
         sc.tongue_class = (torch.rand(P, 1, generator=g) > 0.5).float()
     return dict(
-        P=P, W=W, H=H, bg=torch.ones(3), means3D=sc.xyz, opacities=a["opacities"], tongue_class=sc.tongue_class,
+        P=P, W=W, H=H, bg=torch.tensor(bg, dtype=torch.float32), means3D=sc.xyz, opacities=a["opacities"], tongue_class=sc.tongue_class,
         scales=a["scales"], rotations=a["rotations"], shs=a["shs"], viewmatrix=cam.world_view_transform,
         projmatrix=cam.full_proj_transform, campos=cam.camera_center, tanfovx=math.tan(cam.FoVx * 0.5),
-        tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=kernel_size, scale_modifier=1.0, sh_degree=3)
+        tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=kernel_size, scale_modifier=float(scale_modifier), sh_degree=int(sh_degree))
 
 
 # Exclusion margin of the parity tests (relative distance of a blend decision to its threshold in the ORACLE's forward):
