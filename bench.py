@@ -102,11 +102,11 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
             raise RuntimeError(_lib.last_error())
         # the path's one collective (RCCL over xGMI): 12 bytes, waited for one step later (the stream, not the host,
         # waits), so that ranks are not re-synchronised every step
+        if reducer is not None:  # mean of the ranks' gradients (the collectives were issued during the backward); BEFORE any other
+            reducer.finish()     # collective of the group: a rank may issue its last buckets only here (dist.BucketedGradReducer)
         if inflight:
             inflight.pop().wait()
         inflight.append(D.allreduce_sum_async(stats))
-        if reducer is not None:  # mean of the ranks' gradients (the collectives were issued during the backward)
-            reducer.finish()
         if step.probe is not None:   # untimed passes only: look at the gradients before they are dropped
             step.probe(model)
         for p in params:
@@ -594,6 +594,10 @@ def main():
                          "counts from a separate pass over the first %d items (counting slows K7 to %.3f ms per launch; that is not the time used)" % (n_count, k7_count_ms)}
     valu_roof["quadrant_entries_queued_per_launch"] = k7_work[4]   # (entry, quadrant) pairs the four quadrants' sub-lists hold
     valu_roof["quadrant_entries_per_iteration"] = k7_work[4] / k7_work[0] if k7_work[0] else 0.0   # of 4 slots
+    # 64-byte gradient records K7 added to global memory (its atomics / 16): one per (tile, Gaussian, quadrant) that blended in
+    # the default build, one per (tile, Gaussian, chunk) with -DED3_K7_LDS_TILE=1 (csrc/render_backward.hip)
+    valu_roof["records_added_per_launch"] = k7_work[5]
+    valu_roof["record_atomic_bytes_per_launch"] = k7_work[5] * 64
     # K6 against the same roof (ISA of render_forward_kernel<false,true>, tools/isa.sh, round 3: the per-pixel tests of an iteration
     # -- up to four Gaussians, one per quadrant -- cost 62 four-cycle vector instructions + 4 v_exp_f32, the blend 98 more;
     # iterations in which nothing blends pay the tests only and are not counted: a lower bound of the cycles needed)

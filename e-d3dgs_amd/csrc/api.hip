@@ -63,10 +63,6 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     obtain(chunk, g.point_offsets, P, 128);
     obtain(chunk, g.block_tiles, (P + 255) / 256 + 1, 128);
     obtain(chunk, g.block_kminmax, 2 * ((P + 255) / 256 + 1), 128);
-    obtain(chunk, g.sort_a, 2 * P, 128);
-    obtain(chunk, g.sort_b, 2 * P, 128);
-    obtain(chunk, g.sort_counts, depth_sort_count_words((int)P), 128);
-    obtain(chunk, g.sort_params, 32, 128);
     obtain(chunk, g.depth_keys, P, 128);
     obtain(chunk, g.depth_keys_sorted, P, 128);
     obtain(chunk, g.ids, P, 128);
@@ -74,6 +70,16 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     obtain(chunk, g.offsets_sorted, P, 128);
     g.sort_size = sort_temp_bytes((int)P);
     obtain(chunk, g.sort_space, g.sort_size, 128);
+    // the hand-written depth sort's buffers (binning.hip; opt-in, measured slower than the library's sort): LAST in the layout and
+    // carved only while the switch is on, so the default forward does not carry their 16 B per Gaussian + 48 KB, and everything a
+    // backward or a state view reads sits at the same offset either way
+    g.sort_a = g.sort_b = g.sort_counts = g.sort_params = nullptr;
+    if (opt(OPT_SORT_HANDWRITTEN)) {
+        obtain(chunk, g.sort_a, 2 * P, 128);
+        obtain(chunk, g.sort_b, 2 * P, 128);
+        obtain(chunk, g.sort_counts, depth_sort_count_words((int)P), 128);
+        obtain(chunk, g.sort_params, 32, 128);
+    }
     return g;
 }
 ImageState ImageState::from_chunk(char *&chunk, size_t N, size_t T)
@@ -178,10 +184,18 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
         uint32_t *host = nullptr;            // COUNT_COPY: pinned copy of block_tiles
         size_t cap = 0;
         hipEvent_t ev = nullptr;
-        unsigned long long *word = nullptr;  // host-coherent mail word
-        unsigned long long *counter = nullptr;
-        int dev = -1;
+        struct PerDevice { unsigned long long *word = nullptr, *counter = nullptr; };   // host-coherent mail word, device counter
+        std::vector<PerDevice> devs;         // indexed by device ordinal: a thread that alternates devices re-uses its pairs
         unsigned seq = 0;
+        ~Readback()                          // thread exit: give the pinned and device allocations back (errors ignored: the
+        {                                    // runtime may already be shutting down)
+            for (size_t d = 0; d < devs.size(); d++) {
+                if (devs[d].word) (void)hipHostFree(devs[d].word);
+                if (devs[d].counter) (void)hipFree(devs[d].counter);
+            }
+            if (host) (void)hipHostFree(host);
+            if (ev) (void)hipEventDestroy(ev);
+        }
     } rb;
     const size_t nblk = ((size_t)P + 255) / 256;
     const bool by_copy = opt(OPT_COUNT_COPY) != 0;
@@ -189,17 +203,22 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!by_copy) {
         int dev = 0;
         if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return ED3DGS_ERR_HIP;
-        if (rb.dev != dev) {   // first call of this thread on this device (buffers of another device are left to it: a few bytes)
-            rb.word = nullptr; rb.counter = nullptr;
-            if (!check_hip(hipHostMalloc((void **)&rb.word, 64, hipHostMallocCoherent | hipHostMallocMapped), "count mail word") ||
-                !check_hip(hipMalloc((void **)&rb.counter, 64), "count mail counter") ||
-                !check_hip(hipMemset(rb.counter, 0, 64), "count mail counter")) return ED3DGS_ERR_HIP;
-            *rb.word = 0ull;
-            rb.dev = dev;
+        if ((size_t)dev >= rb.devs.size()) rb.devs.resize((size_t)dev + 1);
+        Readback::PerDevice &pd = rb.devs[(size_t)dev];
+        if (!pd.word) {   // first call of this thread on this device
+            unsigned long long *w = nullptr, *c = nullptr;
+            if (!check_hip(hipHostMalloc((void **)&w, 64, hipHostMallocCoherent | hipHostMallocMapped), "count mail word")) return ED3DGS_ERR_HIP;
+            if (!check_hip(hipMalloc((void **)&c, 64), "count mail counter") || !check_hip(hipMemset(c, 0, 64), "count mail counter")) {
+                (void)hipHostFree(w);
+                if (c) (void)hipFree(c);
+                return ED3DGS_ERR_HIP;
+            }
+            *w = 0ull;
+            pd.word = w; pd.counter = c;
         }
         rb.seq = (rb.seq + 1u) & 0xFFFFFFu;
         if (rb.seq == 0u) rb.seq = 1u;
-        mail.counter = rb.counter; mail.host_word = rb.word; mail.seq = rb.seq;
+        mail.counter = pd.counter; mail.host_word = pd.word; mail.seq = rb.seq;
     }
     launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
                       colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
@@ -237,7 +256,7 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     } else {
         // poll the mail word; every so often ask the stream whether it has failed or (stream idle, word still old) the store
         // is lost, so that a faulted launch ends in an error and not in a spin
-        const volatile unsigned long long *w = rb.word;
+        const volatile unsigned long long *w = mail.host_word;
         unsigned long long v = *w;
         for (unsigned long long spins = 0; (v >> 40) != (unsigned long long)mail.seq; spins++) {
             if ((spins & 0xFFFFu) == 0xFFFFu) {

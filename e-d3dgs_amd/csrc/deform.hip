@@ -5,15 +5,20 @@
 // (get_temporal_embed :53-67), identical for all Gaussians, so its part of the trunk is hoisted to a per-frame
 // vector hb = W1[:, :TD] h_t + b1.
 //
-// How (CDNA4-native, not the reference's 45 torch kernels):
-//  * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in the TRANSPOSED formulation D[out_feature][gaussian] = W * X, so the
-//    accumulator of one layer (feature on the register index, Gaussian on the lane) is directly the B operand of the
-//    next layer: a wave carries a strip of 32 Gaussians through trunk -> head hidden -> head output entirely in
-//    registers, no LDS round trip, no activation ever written to HBM in the forward;
-//  * weights are re-laid once per call into MFMA A-fragment order (one coalesced 256-byte load per MFMA), with the
-//    k-slot permutation f(kk,h) = (kk&3) + 8(kk>>2) + 4h that matches the accumulator's register->feature map;
-//  * backward recomputes the activations per strip, produces the input gradients in registers, stores only what the
-//    weight-gradient reductions need, and reduces dW = G^T X with the same MFMA over split Gaussian ranges.
+// How (CDNA4-native, not the reference's 45 torch kernels; DESIGN.md section 2 "Deformation MLP" has the measurements):
+//  * the TRANSPOSED formulation D[out_feature][gaussian] = W * X on the matrix cores, so the accumulator of one layer (feature
+//    on the register index, Gaussian on the lane) is directly the B operand of the next: a wave carries a strip of 32 Gaussians
+//    through trunk -> head hidden -> head output entirely in registers, no LDS round trip for activations;
+//  * default multiply mode: every fp32 operand split EXACTLY into three bf16 pieces, eight of the nine piece products
+//    accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (deform_forward_b3_kernel<NT,3>, deform_dgrad_kept_bn_kernel<NT,3>,
+//    deform_head_wgrad_tr_kernel<WIDE>); ED3DGS_DEFORM_FP32_MFMA selects the f32-operand kernels (v_mfma_f32_32x32x2_f32),
+//    ED3DGS_DEFORM_BF16X3 the reduced two-piece mode;
+//  * weights are re-laid once per call into MFMA fragment order and reach LDS by LDS-DMA (global_load_lds), double-buffered, the
+//    pieces issued between a tile's MFMAs; the k-slot permutation matches the accumulator's register->feature map;
+//  * training: the forward KEEPS relu(hid), relu(z_k) and their sign masks in the backward's workspace (what autograd keeps for
+//    the reference's modules); the backward re-forms nothing -- the data gradient reads the sign masks, the weight-gradient
+//    kernels the kept tiles, and all of them walk only the rows with a non-zero upstream gradient (deform_active_rows_body).
+//    The stateless backward (activations re-formed per strip) remains for activations_kept = 0 and the other multiply modes.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

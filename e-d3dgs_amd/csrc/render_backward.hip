@@ -8,10 +8,10 @@
 //    pixels run with alpha = G = 0 (updates are the identity, contributions exact zeros) instead of selects;
 //  * sums that are linear in dy (a lane constant) are accumulated without it and scaled once per Gaussian;
 //  * the reference issues 10-25 float atomics per (pixel, Gaussian) pair; here each lane first sums its 4 pixels,
-//    the 16 (or 32) partial sums are reduced inside the quadrant's DPP row with a butterfly that leaves sum k in lane k, the
-//    (up to four) quadrants of a tile add their rows into a chunk-local LDS tile (ds_add_f32, 64 entries x 16 floats), and at
-//    the chunk boundary ONE 64-byte global atomic per touched (tile, Gaussian) entry adds the record (round 4; round 3 issued
-//    one per (tile, Gaussian, quadrant): 2.55 M instead of 0.94 M records per C3 launch, 1.65x the algorithmic HBM traffic);
+//    the 16 (or 32) partial sums are reduced inside the quadrant's DPP row with a butterfly that leaves sum k in lane k, and the
+//    row's 16 lanes add the 64-byte record with one atomic wave-instruction per (tile, Gaussian, quadrant); with
+//    -DED3_K7_LDS_TILE=1 the quadrants' rows meet in a chunk-local LDS tile first (ds_add_f32, 64 entries x 16 floats) and ONE
+//    record per touched (tile, Gaussian) entry leaves at the chunk boundary -- built and measured in round 4, see the macro;
 //  * iteration starts at the tile's largest last-contributor instead of the end of the tile list.
 // Linear post-factors (1/focal on plane gradients, -0.5 on the conic, W/2,H/2 on mean2D) are applied once per
 // Gaussian by the per-Gaussian backward kernel.
@@ -68,6 +68,14 @@ __device__ __forceinline__ void row_transpose_reduce(float (&v)[NV], int lane, f
 #ifndef ED3_K7_WAVES
 #define ED3_K7_WAVES 0
 #endif
+// 1: the quadrants' records meet in a chunk-local LDS tile and ONE 64-byte global atomic per touched (tile, Gaussian) entry is
+// issued at the chunk boundary.  0: every quadrant adds its own record to global memory (round 3).  Measured in
+// round 4: the tile cuts the records 2.55 M -> 0.94 M per C3 launch and the HBM traffic with them, and is
+// SLOWER -- the atomics were never the limiter (365 GB/s of them against ~1.3 TB/s the L2 sustains), the flush's extra
+// instructions and its LDS round trip are paid by a kernel that is bound by instruction issue.
+#ifndef ED3_K7_LDS_TILE
+#define ED3_K7_LDS_TILE 0
+#endif
 template <bool COORD, bool DEPTH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COORD && DEPTH && ED3_K7_WAVES) ? ED3_K7_WAVES : 1), ((!COORD && DEPTH && ED3_K7_WAVES) ? ED3_K7_WAVES : 8)))) render_backward_kernel(
     int W, int H, int gx, const uint32_t *__restrict__ tile_order, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -90,18 +98,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
     __shared__ float4 s_recc[COORD ? 64 * 3 : 1];
     __shared__ uint32_t s_id[64];
     // chunk-local gradient tile: entry j's record, summed over the tile's quadrants; zero outside a chunk's flush
-    __shared__ float s_g[64 * GREC];
-    __shared__ float s_gc[COORD ? 64 * GREC : 1];
+    __shared__ float s_g[ED3_K7_LDS_TILE ? 64 * GREC : 1];
+    __shared__ float s_gc[(ED3_K7_LDS_TILE && COORD) ? 64 * GREC : 1];
+    __shared__ uint32_t s_list[ED3_K7_LDS_TILE ? 64 : 1];   // the chunk's touched entries, compacted (flush)
 
     const int tile = (int)tile_order[blockIdx.x];   // longest tile lists first (tile_order_kernel)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int myq = lane >> 4, li = lane & 15;                       // quadrant-major pixel ownership (raster_common.h)
+#if ED3_K7_LDS_TILE
 #pragma unroll
     for (int i = 0; i < GREC / 4; i++) {
         reinterpret_cast<float4 *>(s_g)[i * 64 + lane] = make_float4(0, 0, 0, 0);
         if (COORD) reinterpret_cast<float4 *>(s_gc)[i * 64 + lane] = make_float4(0, 0, 0, 0);
     }
+#endif
     const uint32_t jshift = 8u * (uint32_t)myq;
     const int px0 = tx * TILE + 8 * (myq & 1) + 4 * (li & 1);
     const int py = ty * TILE + 8 * (myq >> 1) + (li >> 1);
@@ -269,7 +280,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             n_staged += (unsigned)cnt; n_kept += (unsigned)__popcll(live0 | live1 | live2 | live3);
             n_qpairs += (unsigned)(__popcll(live0) + __popcll(live1) + __popcll(live2) + __popcll(live3));
         }
+#if ED3_K7_LDS_TILE
         unsigned long long touched = 0ull;   // entries of the chunk some quadrant added a record to (scalar)
+#endif
         while (live0 | live1 | live2 | live3) {
             // next entry of each quadrant's sub-list (-1: none left), packed into one scalar: a lane picks its byte
             const int j0 = __ffsll(live0) - 1, j1 = __ffsll(live1) - 1, j2 = __ffsll(live2) - 1, j3 = __ffsll(live3) - 1;
@@ -418,41 +431,62 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             acc[G_MX] = mx;
             acc[G_MY] = my;
             acc[G_MZ] = mz;
-            // each quadrant (DPP row) reduces the record of its own Gaussian and adds it to the entry's row of the LDS tile
-            // (ds_add_f32, no return value; quadrants that meet on one entry in the same iteration are serialised by the LDS);
-            // a quadrant in which no pixel blended adds nothing
+            // each quadrant (DPP row) reduces the record of its own Gaussian; a quadrant in which no pixel blended adds nothing.
+            // ED3_K7_LDS_TILE: the row goes to the entry's row of the LDS tile (ds_add_f32, no return value; quadrants that meet
+            // on one entry in the same iteration are serialised by the LDS)
             float z[NV / 16];
             row_transpose_reduce<NV>(acc, lane, z);
             const bool qany = (anyb >> (16 * myq) & 0xFFFFull) != 0ull;
+#if ED3_K7_LDS_TILE
             if (act && qany) {
                 atomicAdd(&s_g[j * GREC + li], z[0]);
                 if (COORD && li < 9) atomicAdd(&s_gc[j * GREC + li], z[NV / 16 - 1]);
             }
             touched |= ((j0 >= 0 && (anyb & 0xFFFFull)) ? 1ull << j0 : 0ull) | ((j1 >= 0 && (anyb >> 16 & 0xFFFFull)) ? 1ull << j1 : 0ull) |
                        ((j2 >= 0 && (anyb >> 32 & 0xFFFFull)) ? 1ull << j2 : 0ull) | ((j3 >= 0 && (anyb >> 48)) ? 1ull << j3 : 0ull);
+#else
+            if (act && qany) {   // round 3: one 64-byte atomic per (tile, Gaussian, quadrant)
+                const uint32_t id = s_id[j];
+                atomicAdd(grec + (size_t)id * GREC + li, z[0]);
+                if (COORD && li < 9) atomicAdd(grec_coord + (size_t)id * GREC + li, z[NV / 16 - 1]);
+            }
+            if (counters) n_flushed += (unsigned)(((j0 >= 0 && (anyb & 0xFFFFull)) ? 1 : 0) + ((j1 >= 0 && (anyb >> 16 & 0xFFFFull)) ? 1 : 0) +
+                                                  ((j2 >= 0 && (anyb >> 32 & 0xFFFFull)) ? 1 : 0) + ((j3 >= 0 && (anyb >> 48)) ? 1 : 0));
+#endif
         }
-        // chunk boundary: ONE 64-byte global atomic per touched entry -- four entries per wave-instruction, a DPP row each; the
-        // row reads its entry's 16 sums, clears them for the next chunk and adds them to the Gaussian's gradient record
-        if (counters) n_flushed += (unsigned)__popcll(touched);
-        while (touched) {
-            const int e0 = __ffsll(touched) - 1; touched &= touched - 1;
-            const int e1 = __ffsll(touched) - 1; touched &= touched - 1;   // (ffs(0) - 1 = -1, and 0 & anything stays 0)
-            const int e2 = __ffsll(touched) - 1; touched &= touched - 1;
-            const int e3 = __ffsll(touched) - 1; touched &= touched - 1;
-            const uint32_t epack = (uint32_t)(e0 & 255) | (uint32_t)(e1 & 255) << 8 | (uint32_t)(e2 & 255) << 16 | (uint32_t)(e3 & 255) << 24;
-            const int e = (int)(epack >> jshift & 255u);
-            if (e != 255) {
-                const uint32_t id = s_id[e];
-                const float v = s_g[e * GREC + li];
-                s_g[e * GREC + li] = 0.f;
-                atomicAdd(grec + (size_t)id * GREC + li, v);
-                if (COORD && li < 9) {
-                    const float vc = s_gc[e * GREC + li];
-                    s_gc[e * GREC + li] = 0.f;
-                    atomicAdd(grec_coord + (size_t)id * GREC + li, vc);
+#if ED3_K7_LDS_TILE
+        // chunk boundary: ONE 64-byte global atomic per touched entry.  The touched entries are compacted into s_list (lane i
+        // writes i at its rank among the set bits); a DPP row then takes an entry, sixteen entries per batch: the rows read their
+        // entries' indices, then the 16 sums and the Gaussian ids, clear the sums for the next chunk and add them to the records
+        if (touched) {
+            const int n = __popcll(touched);
+            if (counters) n_flushed += (unsigned)n;
+            if (touched >> lane & 1ull) s_list[__popcll(touched & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+            __syncthreads();
+            for (int t0 = 0; t0 < n; t0 += 16) {
+                int e[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int ix = t0 + 4 * u + myq; ok[u] = ix < n; e[u] = (int)s_list[ok[u] ? ix : 0]; }
+                float v[4], vc[4];
+                uint32_t gid[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = s_g[e[u] * GREC + li];
+                    gid[u] = s_id[e[u]];
+                    vc[u] = COORD ? s_gc[e[u] * GREC + li] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (ok[u]) {
+                        s_g[e[u] * GREC + li] = 0.f;
+                        atomicAdd(grec + (size_t)gid[u] * GREC + li, v[u]);
+                        if (COORD && li < 9) { s_gc[e[u] * GREC + li] = 0.f; atomicAdd(grec_coord + (size_t)gid[u] * GREC + li, vc[u]); }
+                    }
                 }
             }
         }
+#endif
     }
     if (counters) {
 #pragma unroll

@@ -18,7 +18,8 @@ added and denom grows by 1 (scene/gaussian_model.py:516-518) -- whereas add() pe
 denom += (views that see the Gaussian).  The mean gradient compared with densify_grad_threshold differs between the two (by
 up to a factor N), so clone / split decisions differ.  Both are offered: add() + all_reduce_() = sequential batch_size-1
 iterations over the union of the views; add_batched_step() = the reference's batched step (three collectives per step,
-accumulators replicated, no all_reduce_() before the decision).  tests/test_densify_stats_cpu.py pins each against the
+accumulators replicated, no all_reduce_() before the decision; the summed gradient is scaled by 1 / world_size by default,
+because the reference's batch loss is a mean over the batch while a data-parallel rank's loss is a per-view mean).  tests/test_densify_stats_cpu.py pins each against the
 reference's formulas.
 
 Only what the decision needs is here; the optimizer-state surgery of cat_tensors_to_optimizer / _prune_optimizer
@@ -60,10 +61,17 @@ class DensificationStats:
         self.denom[vf] += 1
 
     @torch.no_grad()
-    def add_batched_step(self, viewspace_point_grad, visibility_filter, radii):
+    def add_batched_step(self, viewspace_point_grad, visibility_filter, radii, loss_scale=None):
         """One optimizer step taken by all ranks together = ONE batch of the reference (train.py:166-190, 346-348, 404-407):
-        SUM the ranks' raw (P, 3) screen-space gradients, OR their visibility, MAX their radii, then one
-        add_densification_stats.  Every rank ends with identical accumulators; do not call all_reduce_() afterwards."""
+        SUM the ranks' (P, 3) screen-space gradients, OR their visibility, MAX their radii, then one
+        add_densification_stats.  Every rank ends with identical accumulators; do not call all_reduce_() afterwards.
+
+        `loss_scale` multiplies the summed gradient.  The reference's batch loss is a MEAN over the stacked views
+        (train.py:195-197: l1_loss(..., keepdim=True).mean()), so each view's gradient at train.py:346-348 already carries
+        1 / batch_size.  A data-parallel rank that backpropagates its own per-view mean loss -- what
+        dist.BucketedGradReducer(average=True) / allreduce_gradients_ assume -- produces gradients batch_size times larger, and
+        the default None = 1 / world_size restores the reference's value (otherwise the mean gradient would meet
+        densify_grad_threshold a factor world_size too high).  Pass 1.0 if the ranks already scaled their losses by 1 / world."""
         if self._reduced:
             raise RuntimeError("DensificationStats.add_batched_step after all_reduce_: call reset() first")
         g = viewspace_point_grad.detach().clone()
@@ -78,6 +86,10 @@ class DensificationStats:
             for dst, src in ((g, wg), (vis, wv), (rad, wr)):
                 if src is not dst:
                     dst.copy_(src)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        scale = (1.0 / world) if loss_scale is None else float(loss_scale)
+        if scale != 1.0:
+            g.mul_(scale)
         vf = vis > 0
         self.max_radii2D[vf] = torch.max(self.max_radii2D[vf], rad[vf])
         self.xyz_gradient_accum[vf] += torch.norm(g[vf, :2], dim=-1, keepdim=True)

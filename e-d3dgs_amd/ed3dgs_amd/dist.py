@@ -186,7 +186,13 @@ class BucketedGradReducer:
     that received no gradient by finish() contribute zeros (every rank must issue the same collectives in the same order:
     buckets are therefore ISSUED in bucket order; one that fills early waits for its predecessors).
     In render()'s graph the deformation node delivers most leaf gradients together at the very end, so what overlaps is the
-    packing of bucket k+1 with the transfer of bucket k and the early SH / opacity gradients with the MLP backward."""
+    packing of bucket k+1 with the transfer of bucket k and the early SH / opacity gradients with the MLP backward.
+
+    Ordering contract: the reducer orders its OWN buckets only.  A rank on which some parameter got no gradient issues that
+    bucket in finish() while another rank issued it from the hook during backward(), so NO other collective of the same process
+    group may be enqueued between backward() and finish() -- call finish() first, then the caller's own collectives (bench.py
+    does).  One backward() per finish(): a hook that fires for a bucket already issued (gradient accumulation over two
+    backward() calls) raises instead of silently dropping the second gradient."""
 
     def __init__(self, params, bucket_bytes=64 << 20, average=True):
         self.params = [p for p in params if p.requires_grad]
@@ -220,6 +226,10 @@ class BucketedGradReducer:
 
     def _landed(self, p):
         i = self.bucket_of[id(p)]
+        if i < self.next_issue or self.missing[i] <= 0:
+            raise RuntimeError("BucketedGradReducer: a gradient landed for a bucket that was already issued or complete -- "
+                               "a second backward() before finish() (gradient accumulation) is not supported: call finish() "
+                               "after every backward(), or use allreduce_gradients_ after the last one")
         self.missing[i] -= 1
         self._issue_ready()
 

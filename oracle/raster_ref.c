@@ -169,8 +169,10 @@ static float g_eig_epsilon = 0.0000001f;
 void ed3ref_set_eig_epsilon(double e) { g_eig_epsilon = (float)e; }
 /* Which decisions feed the per-pixel margin of ed3ref_render_forward, each divided by its own weight before the minimum is
  * taken: [0] the alpha threshold (and power > 0), [1] termination T(1 - alpha) < 1e-4, [2] the median test T > 0.5.
- * Weight 1 for all = the plain smallest relative distance.  A test that tolerates a larger discrepancy in T than in alpha
- * (a long product of factors) passes weights < 1 for [1] and [2]; weight 0 leaves a decision kind out (diagnostics). */
+ * Weight 1 for all = the plain smallest relative distance.  A test that must exclude a WIDER band around the T thresholds than
+ * around the alpha threshold (T is a long product of factors, so its discrepancy is larger) passes weights > 1 for [1] and [2]
+ * (tests/util.py: 1, 5, 5 -- a T decision within 5 x MARGIN of its threshold then reports a margin below MARGIN); weight 0
+ * leaves a decision kind out (diagnostics). */
 static float g_margin_weight[3] = {1.0f, 1.0f, 1.0f};
 void ed3ref_set_margin_weights(double a, double t, double m) { g_margin_weight[0] = (float)a; g_margin_weight[1] = (float)t; g_margin_weight[2] = (float)m; }
 static inline float margin_term(float d, int kind) { return g_margin_weight[kind] > 0.0f ? d / g_margin_weight[kind] : INFINITY; }

@@ -108,8 +108,11 @@ D.destroy()
 
 
 def test_batched_step_matches_the_reference_batch_semantics(tmp_path):
-    """N ranks x one optimizer step = the reference's batch_size N (train.py:166-190, 346-348, 404-407: raw gradients
-    summed over the batch's views, visibility OR-ed, radii maxed, ONE add_densification_stats per step)."""
+    """N ranks x one optimizer step = the reference's batch_size N (train.py:166-190, 346-348, 404-407: gradients
+    summed over the batch's views, visibility OR-ed, radii maxed, ONE add_densification_stats per step).  ADVICE r3: the
+    reference's batch loss is a MEAN over the stacked views (train.py:195-197), so the gradient each view contributes at
+    train.py:346-348 is 1 / batch_size of the gradient of that view's own mean loss -- which is what a data-parallel rank
+    backpropagates (`view(i)[0]` below).  add_batched_step's default therefore scales the summed gradient by 1 / world."""
     script = tmp_path / "bworker.py"
     script.write_text(BATCH_WORKER % dict(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="2", OMP_NUM_THREADS="2")
@@ -132,18 +135,32 @@ def test_batched_step_matches_the_reference_batch_semantics(tmp_path):
         views = [ns["view"](2 * step + r) for r in range(2)]
         g = torch.zeros_like(views[0][0])
         for v in views:
-            g = g + v[0]                                                   # train.py:346-348
+            g = g + v[0] / 2                                               # train.py:346-348 under the batch-mean loss of :195-197
         vis = torch.stack([v[1] for v in views]).any(dim=0)                  # train.py:190
         rad = torch.stack([v[2] for v in views]).max(dim=0).values.float()   # train.py:189
         maxr[vis] = torch.max(maxr[vis], rad[vis])                           # train.py:406
         accum[vis] += torch.norm(g[vis, :2], dim=-1, keepdim=True)           # scene/gaussian_model.py:517
         denom[vis] += 1                                                      # :518
         for v in views:
-            per_view[v[1]] += torch.norm(v[0][v[1], :2], dim=-1, keepdim=True)
+            per_view[v[1]] += torch.norm(v[0][v[1], :2], dim=-1, keepdim=True) / 2
     from ed3dgs_amd import densify_stats as DS
     assert float(denom.sum()) == a["denom"]
     assert abs(float(accum.double().sum()) - a["accum"]) <= 1e-6 * a["accum"]
     assert float(per_view.sum()) > 1.1 * a["accum"]          # and it is NOT the per-view accumulation (add() + all_reduce_())
+
+
+def test_batched_step_loss_scale_argument():
+    """world = 1: the default scale is 1; loss_scale = 0.25 stands for a caller whose per-view losses are 4x the batch's share."""
+    from ed3dgs_amd import densify_stats as DS
+    g = torch.tensor([[3.0, 4.0, 7.0], [0.3, 0.4, 0.7]])
+    vis = torch.tensor([True, True])
+    rad = torch.tensor([3, 4], dtype=torch.int32)
+    a, b = DS.DensificationStats(2, "cpu"), DS.DensificationStats(2, "cpu")
+    a.add_batched_step(g, vis, rad)
+    b.add_batched_step(g, vis, rad, loss_scale=0.25)
+    assert torch.allclose(a.xyz_gradient_accum.reshape(-1), torch.tensor([5.0, 0.5]))
+    assert torch.allclose(b.xyz_gradient_accum.reshape(-1), torch.tensor([1.25, 0.125]))
+    assert torch.allclose(b.abs_gradient_accum.reshape(-1), torch.tensor([1.75, 0.175]))
 
 
 def test_decisions_follow_the_reference_formulas():

@@ -139,6 +139,29 @@ def test_two_rank_hooked_gradient_reducer(tmp_path):
             assert out[:4] == [1.5, 3.0, 1.5, 6.0] and out[4]
 
 
+def test_hooked_reducer_refuses_a_second_backward_before_finish():
+    """gradient accumulation over two backward() calls used to be dropped silently (the bucket had been issued with the
+    first gradient and finish() overwrote .grad with it); now the hook raises."""
+    import pytest
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
+    from ed3dgs_amd import dist as D
+    ps = [torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(3))]
+    red = D.BucketedGradReducer(ps, bucket_bytes=8, average=True)
+    (ps[0].sum() + 2 * ps[1].sum()).backward()
+    with pytest.raises(RuntimeError, match="second backward"):
+        (ps[0].sum() + 2 * ps[1].sum()).backward()
+    red.remove()
+    red2 = D.BucketedGradReducer(ps, bucket_bytes=8, average=True)      # one backward per finish(): fine, twice in a row
+    for _ in range(2):
+        for p in ps:
+            p.grad = None
+        (ps[0].sum() + 2 * ps[1].sum()).backward()
+        red2.finish()
+        assert ps[0].grad.tolist() == [1.0] * 4 and ps[1].grad.tolist() == [2.0] * 3
+    red2.remove()
+
+
 def test_strided_visit_covers_all_cameras():
     sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
     from ed3dgs_amd import dist as D

@@ -36,7 +36,11 @@ def sh_fixture_inputs(deg):
 def cov_fixture_inputs(mod):
     g = _gold("raster_k1_cov3d.npz")
     inp = util.scene_inputs(g["scales"].shape[0], 400, 400, scene_seed=41, scale_modifier=mod)
-    assert np.array_equal(inp["scales"].numpy(), g["scales"]) and np.array_equal(inp["rotations"].numpy(), g["rotations"])
+    # scene 41's activated values as the generating host computed them (torch.exp / normalize differ in the last bit between
+    # CPU models, so they are taken from the fixture rather than recomputed on the testing host)
+    assert np.allclose(inp["scales"].numpy(), g["scales"], rtol=1e-6) and np.allclose(inp["rotations"].numpy(), g["rotations"], atol=1e-6)
+    inp["scales"] = torch.from_numpy(g["scales"].copy())
+    inp["rotations"] = torch.from_numpy(g["rotations"].copy())
     return inp, g["cov3D_mod%02d" % round(mod * 10)]
 
 
