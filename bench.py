@@ -289,7 +289,7 @@ def rehearse(a, D):
     inflight = []
     D.barrier()
     t0 = time.perf_counter()
-    items = [D.strided_item(mine, k) % n_items for k in range(a.steps)]   # the item schedule of the real path
+    items = [D.visit_item(mine, k, wl["cams"], wl["frames"]) % n_items for k in range(a.steps)]   # the item schedule of the real path
     t_step = []
     for k in range(a.steps):
         t1 = time.perf_counter()
@@ -354,7 +354,7 @@ def main():
     n_items = wl["cams"] * wl["frames"]
     my_items = D.shard_items(max(n_items, world), rank, world)
     item_at = (lambda k: my_items[k % len(my_items)] % n_items) if a.sequential_items else \
-              (lambda k: D.strided_item(my_items, k) % n_items)   # coprime stride: a 20-step run visits every camera
+              (lambda k: D.visit_item(my_items, k, wl["cams"], wl["frames"]) % n_items)   # cameras round-robin, frames strided: any run of `cams` steps visits every camera
     ceiling = hbm_ceiling(device) if rank == 0 else None
     mfma_ceiling = None
     if rank == 0:   # what the matrix pipe sustains on this box (untimed): the spec peak the roofline uses is not a sustained rate

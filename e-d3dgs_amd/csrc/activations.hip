@@ -5,6 +5,7 @@
 //   scale = exp(s)                 | with a 3D filter f:  sqrt(exp(s)^2 + f^2)
 //   opac  = sigmoid(o)             | with a 3D filter f:  sigmoid(o) * sqrt(prod exp(s)^2 / prod (exp(s)^2 + f^2))
 #include "common.h"
+#include "activation_math.h"
 
 namespace ed3 {
 
@@ -17,21 +18,12 @@ __global__ void __launch_bounds__(256) activations_forward_kernel(int P, const f
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const float4 q = reinterpret_cast<const float4 *>(rot_raw)[i];
-    const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-    reinterpret_cast<float4 *>(rot)[i] = make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);
-    const float e0 = expf(s_log[3 * i]), e1 = expf(s_log[3 * i + 1]), e2 = expf(s_log[3 * i + 2]);
-    const float sg = 1.0f / (1.0f + expf(-o_logit[i]));
-    if (filter3d) {
-        const float f2 = filter3d[i] * filter3d[i];
-        const float s0 = e0 * e0, s1 = e1 * e1, s2 = e2 * e2;
-        const float a0 = s0 + f2, a1 = s1 + f2, a2 = s2 + f2;
-        scales[3 * i] = sqrtf(a0); scales[3 * i + 1] = sqrtf(a1); scales[3 * i + 2] = sqrtf(a2);
-        opac[i] = sg * sqrtf((s0 * s1 * s2) / (a0 * a1 * a2));
-    } else {
-        scales[3 * i] = e0; scales[3 * i + 1] = e1; scales[3 * i + 2] = e2;
-        opac[i] = sg;
-    }
+    reinterpret_cast<float4 *>(rot)[i] = act_normalize(reinterpret_cast<const float4 *>(rot_raw)[i]);
+    const float sl[3] = {s_log[3 * i], s_log[3 * i + 1], s_log[3 * i + 2]};
+    float sc[3], op;
+    act_scale_opacity(sl, o_logit[i], filter3d != nullptr, filter3d ? filter3d[i] : 0.f, sc, op);
+    scales[3 * i] = sc[0]; scales[3 * i + 1] = sc[1]; scales[3 * i + 2] = sc[2];
+    opac[i] = op;
 }
 
 __global__ void __launch_bounds__(256) activations_backward_kernel(int P, const float *__restrict__ s_log,
@@ -47,40 +39,32 @@ __global__ void __launch_bounds__(256) activations_backward_kernel(int P, const 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    {   // normalize: d/dx (x / n) = (g - n_hat (n_hat . g)) / n   (n clamped at 1e-12 -> plain scaling)
-        const float4 q = reinterpret_cast<const float4 *>(rot_raw)[i];
-        const float4 g = g_rot ? reinterpret_cast<const float4 *>(g_rot)[i] : make_float4(0, 0, 0, 0);
-        const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        float4 o;
-        if (n > 1e-12f) {
-            const float inv = 1.0f / n;
-            const float hx = q.x * inv, hy = q.y * inv, hz = q.z * inv, hw = q.w * inv;
-            const float d = hx * g.x + hy * g.y + hz * g.z + hw * g.w;
-            o = make_float4((g.x - hx * d) * inv, (g.y - hy * d) * inv, (g.z - hz * d) * inv, (g.w - hw * d) * inv);
-        } else {
-            o = make_float4(g.x / 1e-12f, g.y / 1e-12f, g.z / 1e-12f, g.w / 1e-12f);
-        }
-        reinterpret_cast<float4 *>(g_rot_raw)[i] = o;
-    }
-    const float e[3] = {expf(s_log[3 * i]), expf(s_log[3 * i + 1]), expf(s_log[3 * i + 2])};
+    const float4 g = g_rot ? reinterpret_cast<const float4 *>(g_rot)[i] : make_float4(0, 0, 0, 0);
+    reinterpret_cast<float4 *>(g_rot_raw)[i] = act_normalize_bwd(reinterpret_cast<const float4 *>(rot_raw)[i], g);
+    const float sl[3] = {s_log[3 * i], s_log[3 * i + 1], s_log[3 * i + 2]};
     const float gs[3] = {g_scales ? g_scales[3 * i] : 0.f, g_scales ? g_scales[3 * i + 1] : 0.f, g_scales ? g_scales[3 * i + 2] : 0.f};
-    const float go = g_opac ? g_opac[i] : 0.f;
-    const float sg = 1.0f / (1.0f + expf(-o_logit[i]));
-    if (filter3d) {
-        const float f2 = filter3d[i] * filter3d[i];
-        float s2[3], a2[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { s2[k] = e[k] * e[k]; a2[k] = s2[k] + f2; }
-        const float coef = sqrtf((s2[0] * s2[1] * s2[2]) / (a2[0] * a2[1] * a2[2]));
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            g_s_log[3 * i + k] = gs[k] * s2[k] / sqrtf(a2[k]) + go * sg * coef * (1.0f - s2[k] / a2[k]);
-        g_o_logit[i] = go * coef * sg * (1.0f - sg);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; k++) g_s_log[3 * i + k] = gs[k] * e[k];
-        g_o_logit[i] = go * sg * (1.0f - sg);
-    }
+    float gl[3], gol;
+    act_scale_opacity_bwd(sl, o_logit[i], filter3d != nullptr, filter3d ? filter3d[i] : 0.f, gs, g_opac ? g_opac[i] : 0.f, gl, gol);
+    g_s_log[3 * i] = gl[0]; g_s_log[3 * i + 1] = gl[1]; g_s_log[3 * i + 2] = gl[2];
+    g_o_logit[i] = gol;
+}
+
+// for the deformation entry points (deform.hip): the stand-alone launches where a kernel variant does not apply the activations itself
+bool launch_activations_forward(int P, const float *s_log, const float *rot_raw, const float *o_logit, const float *filter3d,
+                                float *scales, float *rot, float *opac, hipStream_t s)
+{
+    if (P <= 0) return true;
+    hipLaunchKernelGGL(activations_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, s_log, rot_raw, o_logit, filter3d, scales, rot, opac);
+    return check_hip(hipGetLastError(), "activations forward");
+}
+bool launch_activations_backward(int P, const float *s_log, const float *rot_raw, const float *o_logit, const float *filter3d,
+                                 const float *g_scales, const float *g_rot, const float *g_opac, float *g_s_log, float *g_rot_raw,
+                                 float *g_o_logit, hipStream_t s)
+{
+    if (P <= 0) return true;
+    hipLaunchKernelGGL(activations_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, s_log, rot_raw, o_logit, filter3d,
+                       g_scales, g_rot, g_opac, g_s_log, g_rot_raw, g_o_logit);
+    return check_hip(hipGetLastError(), "activations backward");
 }
 
 }  // namespace ed3

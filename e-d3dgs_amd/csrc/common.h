@@ -146,6 +146,12 @@ void launch_render_backward(int W, int H, const uint32_t *ranges, const uint32_t
                             const float *dL_dpix, const float *dL_dcoord, const float *dL_dmcoord,
                             const float *dL_ddepth, const float *dL_dmdepth, const float *dL_dalpha,
                             const float *dL_dnormal, float *grec, float *grec_coord, hipStream_t s, unsigned long long *counters = nullptr);
+// activations.hip (stand-alone launches of activation_math.h)
+bool launch_activations_forward(int P, const float *s_log, const float *rot_raw, const float *o_logit, const float *filter3d,
+                                float *scales, float *rot, float *opac, hipStream_t s);
+bool launch_activations_backward(int P, const float *s_log, const float *rot_raw, const float *o_logit, const float *filter3d,
+                                 const float *g_scales, const float *g_rot, const float *g_opac, float *g_s_log, float *g_rot_raw,
+                                 float *g_o_logit, hipStream_t s);
 // integrate.hip (point integration: K12-K14)
 size_t integrate_point_bytes(int PN, int width, int height);
 size_t integrate_workspace_bytes(int R, int width, int height);

@@ -30,6 +30,7 @@
 
 #include "common.h"
 #include "deform_common.h"
+#include "activation_math.h"
 
 namespace ed3 {
 
@@ -84,6 +85,7 @@ struct DeformDev {
     const float *emb, *xyz, *scales, *rot, *opacity, *sh;
     const float *sh_rest;   // NULL: sh is [P][n_sh][3]; else sh is the DC term [P][1][3] and this the rest [P][n_sh - 1][3]
     float *out[5], *sub[5];
+    float *act[3];   // optional: the activated final scales / rotations / opacity (activation_math.h), written by the forward's epilogue
     // backward
     const float *g[5], *gs[5];
     float *A[2], *ZR[2], *GZ[2], *GHID[2];  // [P][W], [5][P][W], [5][P][W], [P][W]
@@ -908,6 +910,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                     if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
                     if (w3) dst[3][g] = co;
+                    // the rasterizer's inputs straight from the strip's registers (gaussian_renderer/__init__.py:77-81: normalize,
+                    // exp, sigmoid -- the 3D-filter variant couples opacity to the scales and takes the stand-alone launch): the
+                    // owner of a head's tensor writes its activated twin as well
+                    if (s == 1 && d.act[0]) {
+                        if (w1) {
+#pragma unroll
+                            for (int i = 0; i < 3; i++) d.act[0][(size_t)g * 3 + i] = expf(cs[i]);
+                        }
+                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)g * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
+                        if (w3) d.act[2][g] = act_sigmoid(co);
+                    }
                 }
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) {
@@ -1251,6 +1264,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                     if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
                     if (w3) dst[3][g] = co;
+                    // the rasterizer's inputs straight from the strip's registers (gaussian_renderer/__init__.py:77-81: normalize,
+                    // exp, sigmoid -- the 3D-filter variant couples opacity to the scales and takes the stand-alone launch): the
+                    // owner of a head's tensor writes its activated twin as well
+                    if (s == 1 && d.act[0]) {
+                        if (w1) {
+#pragma unroll
+                            for (int i = 0; i < 3; i++) d.act[0][(size_t)g * 3 + i] = expf(cs[i]);
+                        }
+                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)g * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
+                        if (w3) d.act[2][g] = act_sigmoid(co);
+                    }
                 }
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) {
@@ -2118,7 +2142,9 @@ struct HeadWgradArgs {
     int P, njobs;
     const int *rows, *n_act;      // active rows (NULL: all): slabs are 32 list entries, every per-Gaussian read is a gather
     unsigned long long *timing;   // diagnostic (ED3DGS_WG_TIMING): per-phase cycle sums of block 0's waves, [wave][8]
-    int ablate;   // diagnostic (ED3DGS_WG_ABLATE; results are then wrong): 1 no DMA after the first slab, 2 no dW2 MFMAs, 4 no split pass
+    int ablate;   // diagnostic (ED3DGS_WG_ABLATE; results are then wrong): 1 no DMA after the first slab, 2 no dW2 MFMAs, 4 no split pass,
+                  // 8 emulate "3 compute waves + 1 loader wave": wave 3 issues every LDS-DMA piece and computes nothing (its m-tile of
+                  // dW2 and its feature tile of dW3 stay zero), waves 0-2 issue none -- time x 4/3 against the plain launch prices the design
     int blk_begin[MAXHEADJOBS + 1];
     HeadJob job[MAXHEADJOBS];
 };
@@ -2560,7 +2586,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int i = 0; i < 4; i++) ro[i] = (unsigned)rid[8 * i + 2 * wave + h] * (unsigned)HJ_W + (unsigned)(c * 4);
     };
     // 16 KB = 16 DMA instructions of 1 KB (2 rows), 4 per wave; rows past the range re-read the last row
-    auto dma_slab = [&](const float *src, float *dst) {
+    const bool loader_mode = (a.ablate & 8) != 0;     // wave-uniform (diagnostic): wave 3 loads for the block
+    auto dma_slab = [&](const float *src, float *dst, const int *rid) {
+        if (loader_mode) {
+            if (wave != 3) return;
+#pragma unroll
+            for (int piece = 0; piece < 16; piece++) {   // piece = rows 2 piece, 2 piece + 1 of the slab
+                const unsigned o = (unsigned)rid[2 * piece + h] * (unsigned)HJ_W + (unsigned)(c * 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int piece = i * 4 + wave;
@@ -2618,8 +2655,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (tid < 32) rid0[tid] = ids_next;
     __syncthreads();
     row_offsets(rid0);
-    dma_slab(J.ZR, zbuf0);
-    if constexpr (AREG) load_a(); else dma_slab(J.A, astage);
+    dma_slab(J.ZR, zbuf0, rid0);
+    if constexpr (AREG) load_a(); else dma_slab(J.A, astage, rid0);
     load_g(rid0);
     ids_next = fetch_ids(min(1, nslab - 1));
     auto body = [&](auto bufc, int slab) {
@@ -2655,12 +2692,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         WG_MARK(2);
         if (slab + 1 < nslab && !(a.ablate & 1)) {
             row_offsets(rid_nx);
-            dma_slab(J.ZR, BUF ? zbuf0 : zbuf1);
-            if constexpr (AREG) load_a(); else dma_slab(J.A, astage);
+            dma_slab(J.ZR, BUF ? zbuf0 : zbuf1, rid_nx);
+            if constexpr (AREG) load_a(); else dma_slab(J.A, astage, rid_nx);
             load_g(rid_nx);
         }
         ids_next = fetch_ids(min(slab + 2, nslab - 1));
         WG_MARK(3);
+        if (loader_mode && wave == 3) return;              // the loader computes nothing (both barriers of the slab are behind it)
 
         // g_z tile of this wave (Gaussian on the register index), masked by relu(z) > 0
         f32x16 dd = zero_acc();
@@ -3019,6 +3057,12 @@ struct ActiveArgs {
     float *sh_dc, *sh_rest;       // optional split output of g_sh + gs_sh
     int *rows, *ctr;
     const float *dummy;           // >= 16 readable bytes standing in for absent tensors
+    // activation backward folded into this pass (ed3dgs_deform_backward_activated): act_g = dL/d(activated scales, rotations,
+    // opacity) (NULL = zero), act_raw = the forward's raw outputs, act_out = dL/d(raw) written for every Gaussian; the data- and
+    // weight-gradient kernels then read act_out as the heads' upstream gradients (g[2], g[4], g[6] point at it)
+    int act_on;
+    const float *act_g[3], *act_raw[3];
+    float *act_out[3];
 };
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte access at a 4-byte aligned address
 __device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, const int bx)
@@ -3038,10 +3082,37 @@ __device__ __forceinline__ void deform_active_rows_body(const ActiveArgs &a, con
         float v[8][4];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const int nkq = a.g[q] ? a.nk[q] : 1;                        // absent: one dummy word, four times
-            const float *p = a.g[q] ? a.g[q] + (size_t)(g0 + row) * nkq : dummy;
+            const bool have = a.g[q] && !(a.act_on && (q == 2 || q == 4 || q == 6));   // (those three are formed below, not loaded)
+            const int nkq = have ? a.nk[q] : 1;                          // absent: one dummy word, four times
+            const float *p = have ? a.g[q] + (size_t)(g0 + row) * nkq : dummy;
 #pragma unroll
             for (int j = 0; j < 4; j++) v[q][j] = p[min(j, nkq - 1)];   // values past nk re-read the last one
+        }
+        if (a.act_on) {   // (uniform) dL/d(activated) -> dL/d(raw) for the final scales / rotations / opacity of this Gaussian
+            const size_t gr = (size_t)(g0 + row);
+            float ga[3][4], raw[3][4];
+            const int nka[3] = {3, 4, 1};
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const float *pg = a.act_g[t] ? a.act_g[t] + gr * nka[t] : dummy;
+                const float *pr = a.act_raw[t] + gr * nka[t];
+                const int ng = a.act_g[t] ? nka[t] : 1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ga[t][j] = pg[min(j, ng - 1)]; raw[t][j] = pr[min(j, nka[t] - 1)]; }
+                if (!a.act_g[t]) { ga[t][0] = ga[t][1] = ga[t][2] = ga[t][3] = 0.f; }
+            }
+            float gl[3], gol;
+            act_scale_opacity_bwd(raw[0], raw[2][0], false, 0.f, ga[0], ga[2][0], gl, gol);
+            const float4 gq = act_normalize_bwd(make_float4(raw[1][0], raw[1][1], raw[1][2], raw[1][3]), make_float4(ga[1][0], ga[1][1], ga[1][2], ga[1][3]));
+            if (tid < nrow) {
+                a.act_out[0][gr * 3] = gl[0]; a.act_out[0][gr * 3 + 1] = gl[1]; a.act_out[0][gr * 3 + 2] = gl[2];
+                *reinterpret_cast<float4 *>(a.act_out[1] + gr * 4) = gq;
+                a.act_out[2][gr] = gol;
+            }
+            // the row flags look at what the kernels behind this pass will read
+            v[2][0] = gl[0]; v[2][1] = gl[1]; v[2][2] = v[2][3] = gl[2];
+            v[4][0] = gq.x; v[4][1] = gq.y; v[4][2] = gq.z; v[4][3] = gq.w;
+            v[6][0] = v[6][1] = v[6][2] = v[6][3] = gol;
         }
         bool nz = false;
 #pragma unroll
@@ -3422,14 +3493,17 @@ size_t ed3dgs_deform_workspace_bytes(const ed3dgs_deform_cfg *cfg, int for_backw
     return carve(cfg, for_backward != 0, nullptr, nullptr);
 }
 
-int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
-                          const float *const params[2], const float *embedding, const float *xyz, const float *scales,
-                          const float *rot, const float *opacity, const float *sh, const float *sh_rest, float *out_xyz,
-                          float *out_scales, float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
-                          float *sub_rot, float *sub_opacity, float *sub_sh, char *workspace, size_t workspace_bytes,
-                          int keep_activations, void *stream)
+static int deform_forward_impl(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                               const float *const params[2], const float *embedding, const float *xyz, const float *scales,
+                               const float *rot, const float *opacity, const float *sh, const float *sh_rest, float *out_xyz,
+                               float *out_scales, float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
+                               float *sub_rot, float *sub_opacity, float *sub_sh, const float *filter_3D, float *act_scales,
+                               float *act_rot, float *act_opacity, char *workspace, size_t workspace_bytes,
+                               int keep_activations, void *stream)
 {
     if (!validate(cfg, "ed3dgs_deform_forward")) return ED3DGS_ERR_INVALID;
+    const bool want_act = act_scales || act_rot || act_opacity;
+    if (want_act && !(act_scales && act_rot && act_opacity)) { set_error("ed3dgs_deform_forward_activated: act_* must be all set or all NULL"); return ED3DGS_ERR_INVALID; }
     if (cfg->P == 0) return 0;
     if (!table || !offsets || !embedding || !xyz || !scales || !rot || !opacity || !sh || !out_xyz || !out_scales ||
         !out_rot || !out_opacity || !out_sh || !workspace) { set_error("ed3dgs_deform_forward: null pointer"); return ED3DGS_ERR_INVALID; }
@@ -3457,6 +3531,7 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         for (int i = 0; i < 5; i++) { io.base[i] = bases[i]; io.out[i] = outs_[i]; io.sub[i] = have_sub ? subs_[i] : nullptr; }
         for (int st = 0; st < 2; st++) { io.params[st] = params[st]; io.hb[st] = w.frag[st] + fld.HB; }
         if (!deep_forward(cfg, io, w.deep, s)) return ED3DGS_ERR_HIP;
+        if (want_act && !launch_activations_forward(cfg->P, out_scales, out_rot, out_opacity, filter_3D, act_scales, act_rot, act_opacity, s)) return ED3DGS_ERR_HIP;
         return keep ? 1 : 0;
     }
     DeformDev d;
@@ -3464,6 +3539,10 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
     fill_dev(cfg, d, false);
     d.frag[0] = w.frag[0]; d.frag[1] = w.frag[1];
     d.keep = keep ? 1 : 0;
+    // the fused kernels apply normalize / exp / sigmoid in their epilogue; the 3D-filter variant (opacity depends on the final
+    // scales, which a tail unit that owns the opacity head does not hold) takes the stand-alone launch behind the kernel
+    const bool act_in_kernel = want_act && !filter_3D;
+    if (act_in_kernel) { d.act[0] = act_scales; d.act[1] = act_rot; d.act[2] = act_opacity; }
     static unsigned long long *fwd_timing = nullptr;
     if (opt(OPT_FWD_TIMING) && !fwd_timing) (void)hipMalloc((void **)&fwd_timing, 32 * sizeof(unsigned long long));
     d.timing = opt(OPT_FWD_TIMING) ? fwd_timing : nullptr;
@@ -3508,16 +3587,51 @@ int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, cons
         }
     }
     if (!check_hip(hipGetLastError(), "deform forward")) return ED3DGS_ERR_HIP;
+    if (want_act && !act_in_kernel &&
+        !launch_activations_forward(cfg->P, out_scales, out_rot, out_opacity, filter_3D, act_scales, act_rot, act_opacity, s)) return ED3DGS_ERR_HIP;
     return keep ? 1 : 0;
 }
 
-int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+int ed3dgs_deform_forward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                          const float *const params[2], const float *embedding, const float *xyz, const float *scales,
+                          const float *rot, const float *opacity, const float *sh, const float *sh_rest, float *out_xyz,
+                          float *out_scales, float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz, float *sub_scales,
+                          float *sub_rot, float *sub_opacity, float *sub_sh, char *workspace, size_t workspace_bytes,
+                          int keep_activations, void *stream)
+{
+    return deform_forward_impl(cfg, table, offsets, params, embedding, xyz, scales, rot, opacity, sh, sh_rest, out_xyz, out_scales,
+                               out_rot, out_opacity, out_sh, sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh, nullptr, nullptr,
+                               nullptr, nullptr, workspace, workspace_bytes, keep_activations, stream);
+}
+
+int ed3dgs_deform_forward_activated(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                                    const float *const params[2], const float *embedding, const float *xyz, const float *scales,
+                                    const float *rot, const float *opacity, const float *sh, const float *sh_rest, float *out_xyz,
+                                    float *out_scales, float *out_rot, float *out_opacity, float *out_sh, float *sub_xyz,
+                                    float *sub_scales, float *sub_rot, float *sub_opacity, float *sub_sh, const float *filter_3D,
+                                    float *act_scales, float *act_rot, float *act_opacity, char *workspace, size_t workspace_bytes,
+                                    int keep_activations, void *stream)
+{
+    if (!act_scales || !act_rot || !act_opacity) { set_error("ed3dgs_deform_forward_activated: null act_* pointer"); return ED3DGS_ERR_INVALID; }
+    return deform_forward_impl(cfg, table, offsets, params, embedding, xyz, scales, rot, opacity, sh, sh_rest, out_xyz, out_scales,
+                               out_rot, out_opacity, out_sh, sub_xyz, sub_scales, sub_rot, sub_opacity, sub_sh, filter_3D, act_scales,
+                               act_rot, act_opacity, workspace, workspace_bytes, keep_activations, stream);
+}
+
+// act (optional): the activation backward in front of the network's (ed3dgs_deform_backward_activated)
+struct ActBackward {
+    const float *raw[3];   // the forward's raw final scales [P,3], rotations [P,4], opacity [P,1]
+    const float *filter_3D;
+    const float *ga[3];    // dL/d(activated ...), NULL = zero
+    float *out[3];         // dL/d(raw ...), written for every Gaussian
+};
+static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
                            const float *const params[2], const float *embedding, const float *g_xyz,
                            const float *g_scales, const float *g_rot, const float *g_opacity, const float *g_sh,
                            const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
                            const float *gs_sh, float *const gparams[2], float *g_table, float *g_offsets,
                            float *g_embedding, float *g_base_sh_dc, float *g_base_sh_rest, char *workspace,
-                           size_t workspace_bytes, int activations_kept, void *stream)
+                           size_t workspace_bytes, int activations_kept, void *stream, const ActBackward *act)
 {
     if (!validate(cfg, "ed3dgs_deform_backward")) return ED3DGS_ERR_INVALID;
     const bool deep = use_deep(cfg);
@@ -3569,6 +3683,15 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     ActiveArgs aa;
     std::memset(&aa, 0, sizeof aa);
     const bool split_sh = g_base_sh_dc != nullptr;
+    // The activation backward.  In the default configuration it is part of the pass that reads the upstream gradients anyway
+    // (deform_active_rows_body, blocks of the prepare launch); the 3D-filter variant and the configurations whose backward walks
+    // every row take the stand-alone launch.  Either way the raw-space gradients are in act->out from here on.
+    const bool act_in_pass = act && compact && !act->filter_3D;
+    if (act) {
+        if (!act_in_pass && !launch_activations_backward(cfg->P, act->raw[0], act->raw[1], act->raw[2], act->filter_3D, act->ga[0], act->ga[1],
+                                                         act->ga[2], act->out[0], act->out[1], act->out[2], s)) return ED3DGS_ERR_HIP;
+        g_scales = act->out[0]; g_rot = act->out[1]; g_opacity = act->out[2];
+    }
     if (compact || split_sh) {
         const float *gin[5] = {g_xyz, g_scales, g_rot, g_opacity, g_sh};
         const float *gsin[5] = {gs_xyz, gs_scales, gs_rot, gs_opacity, gs_sh};
@@ -3586,6 +3709,10 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
         if (compact) {
             aa.rows = w.rows; aa.ctr = w.ctr;
             d.rows = w.rows; d.n_act = w.ctr + 2;
+        }
+        if (act_in_pass) {
+            aa.act_on = 1;
+            for (int t = 0; t < 3; t++) { aa.act_g[t] = act->ga[t]; aa.act_raw[t] = act->raw[t]; aa.act_out[t] = act->out[t]; }
         }
     }
     if (!run_prep(cfg, table, offsets, params, w, true, s, activations_kept != 0 && !deep, &za, (compact || split_sh) ? &aa : nullptr)) return ED3DGS_ERR_HIP;
@@ -3816,6 +3943,41 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
     hipLaunchKernelGGL(deform_frame_bwd_kernel, dim3((cfg->TD + 63) / 64, 2), dim3(256), 0, s, fb);
     if (!check_hip(hipGetLastError(), "deform frame backward")) return ED3DGS_ERR_HIP;
     return 0;
+}
+
+int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                           const float *const params[2], const float *embedding, const float *g_xyz,
+                           const float *g_scales, const float *g_rot, const float *g_opacity, const float *g_sh,
+                           const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
+                           const float *gs_sh, float *const gparams[2], float *g_table, float *g_offsets,
+                           float *g_embedding, float *g_base_sh_dc, float *g_base_sh_rest, char *workspace,
+                           size_t workspace_bytes, int activations_kept, void *stream)
+{
+    return deform_backward_impl(cfg, table, offsets, params, embedding, g_xyz, g_scales, g_rot, g_opacity, g_sh, gs_xyz, gs_scales,
+                                gs_rot, gs_opacity, gs_sh, gparams, g_table, g_offsets, g_embedding, g_base_sh_dc, g_base_sh_rest,
+                                workspace, workspace_bytes, activations_kept, stream, nullptr);
+}
+
+int ed3dgs_deform_backward_activated(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                                     const float *const params[2], const float *embedding, const float *g_xyz, const float *g_sh,
+                                     const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
+                                     const float *gs_sh, const float *raw_scales, const float *raw_rot, const float *raw_opacity,
+                                     const float *filter_3D, const float *ga_scales, const float *ga_rot, const float *ga_opacity,
+                                     float *g_raw_scales, float *g_raw_rot, float *g_raw_opacity, float *const gparams[2],
+                                     float *g_table, float *g_offsets, float *g_embedding, float *g_base_sh_dc, float *g_base_sh_rest,
+                                     char *workspace, size_t workspace_bytes, int activations_kept, void *stream)
+{
+    if (cfg && cfg->P > 0 && (!raw_scales || !raw_rot || !raw_opacity || !g_raw_scales || !g_raw_rot || !g_raw_opacity)) {
+        set_error("ed3dgs_deform_backward_activated: null raw_* / g_raw_* pointer"); return ED3DGS_ERR_INVALID;
+    }
+    ActBackward act;
+    act.raw[0] = raw_scales; act.raw[1] = raw_rot; act.raw[2] = raw_opacity;
+    act.filter_3D = filter_3D;
+    act.ga[0] = ga_scales; act.ga[1] = ga_rot; act.ga[2] = ga_opacity;
+    act.out[0] = g_raw_scales; act.out[1] = g_raw_rot; act.out[2] = g_raw_opacity;
+    return deform_backward_impl(cfg, table, offsets, params, embedding, g_xyz, nullptr, nullptr, nullptr, g_sh, gs_xyz, gs_scales, gs_rot,
+                                gs_opacity, gs_sh, gparams, g_table, g_offsets, g_embedding, g_base_sh_dc, g_base_sh_rest, workspace,
+                                workspace_bytes, activations_kept, stream, &act);
 }
 
 }  // extern "C"

@@ -52,7 +52,7 @@ def lib():
               "ed3dgs_knn_workspace_bytes", "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes"):
         getattr(L, n).restype = C.c_size_t
     for n in ("ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible", "ed3dgs_state_view_get",
-              "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
+              "ed3dgs_deform_forward", "ed3dgs_deform_backward", "ed3dgs_deform_forward_activated", "ed3dgs_deform_backward_activated", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
               "ed3dgs_activations_backward", "ed3dgs_compute_3d_filter", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts",
               "ed3dgs_set_option", "ed3dgs_get_option", "ed3dgs_binning_path", "ed3dgs_profile_tile_counts",
               "ed3dgs_measure_mfma_ceiling"):
@@ -67,7 +67,7 @@ EXPORTS = (
     "ed3dgs_last_error", "ed3dgs_abi_version", "ed3dgs_geometry_bytes", "ed3dgs_image_bytes", "ed3dgs_binning_bytes",
     "ed3dgs_backward_workspace_bytes", "ed3dgs_rasterize_forward", "ed3dgs_rasterize_backward", "ed3dgs_mark_visible",
     "ed3dgs_state_view_get", "ed3dgs_deform_param_count", "ed3dgs_deform_workspace_bytes", "ed3dgs_deform_forward",
-    "ed3dgs_deform_backward", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
+    "ed3dgs_deform_backward", "ed3dgs_deform_forward_activated", "ed3dgs_deform_backward_activated", "ed3dgs_profile_begin", "ed3dgs_profile_end", "ed3dgs_profile_begin_slots", "ed3dgs_profile_end_slots", "ed3dgs_activations_forward",
     "ed3dgs_activations_backward", "ed3dgs_filter3d_workspace_bytes", "ed3dgs_compute_3d_filter",
     "ed3dgs_knn_workspace_bytes", "ed3dgs_knn_mean_dist2", "ed3dgs_knn_neighbours",
     "ed3dgs_integrate_point_bytes", "ed3dgs_integrate_workspace_bytes", "ed3dgs_integrate", "ed3dgs_image_stats", "ed3dgs_profile_tile_backward_counts",

@@ -100,6 +100,42 @@ def strided_item(my_items, k):
     return my_items[(k * visit_stride(n)) % n]
 
 
+_ORDER_CACHE = {}
+
+
+def visit_order(my_items, n_cams, n_frames):
+    """The order in which a rank renders its shard: round-robin over the CAMERAS present in the shard, and inside a camera its
+    items with visit_stride -- a permutation of the shard whose every run of C consecutive steps sees C different cameras (C = the
+    cameras of the shard), so that a short timed run (the driver's 20 steps) covers every camera on every rank whatever the
+    workload's shape (C4: 15 cameras x 300 frames over 8 ranks, where a single stride over the flat shard misses two of them).
+    train.py:134-187 draws its views at random; this is the deterministic stand-in."""
+    key = (len(my_items), my_items[0] if my_items else -1, my_items[-1] if my_items else -1, n_cams, n_frames)
+    order = _ORDER_CACHE.get(key)
+    if order is None:
+        by_cam = {}
+        for i in my_items:
+            by_cam.setdefault(item_of(i, n_cams, n_frames)[0], []).append(i)
+        lists = []
+        for c in sorted(by_cam):
+            v = by_cam[c]
+            st = visit_stride(len(v))
+            lists.append([v[(k * st) % len(v)] for k in range(len(v))])
+        order, k = [], 0
+        while len(order) < len(my_items):
+            for v in lists:
+                if k < len(v):
+                    order.append(v[k])
+            k += 1
+        _ORDER_CACHE[key] = order
+    return order
+
+
+def visit_item(my_items, k, n_cams, n_frames):
+    """The k-th item a rank renders (visit_order, cyclic)."""
+    order = visit_order(my_items, n_cams, n_frames)
+    return order[k % len(order)]
+
+
 def gather_per_rank(value, device):
     """[value of rank 0, ..., value of rank N-1] on every rank (one SUM all-reduce of a one-hot vector)."""
     world = dist.get_world_size() if dist.is_initialized() else 1

@@ -36,7 +36,9 @@ class _DeformFn(torch.autograd.Function):
     `sh_rest` None) or as the reference stores it (`sh` = _features_dc [P,1,3], `sh_rest` = _features_rest [P,n_sh-1,3])."""
 
     @staticmethod
-    def forward(ctx, cfgd, want_sub, keep, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh, sh_rest):
+    def forward(ctx, cfgd, want_sub, keep, act, table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh, sh_rest):
+        """act: None, or (filter_3D or None,) -- also return render()'s activated scales / rotations / opacity
+        (ed3dgs_deform_forward_activated: written by the MLP kernel's epilogue), after the other outputs."""
         L = _lib.lib()
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward (NULL = zero for the C ABI)
         cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
@@ -56,21 +58,32 @@ class _DeformFn(torch.autograd.Function):
         ws_bytes = L.ed3dgs_deform_workspace_bytes(C.byref(cfg), C.c_int(1 if keep else 0))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
-        rc = L.ed3dgs_deform_forward(
-            C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
-            _ptr(sh_), _ptr(shr_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
-            C.c_int(1 if keep else 0), _lib.raw_stream(dev))
+        acts, filt = [], None
+        if act is None:
+            rc = L.ed3dgs_deform_forward(
+                C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
+                _ptr(sh_), _ptr(shr_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(ws), C.c_size_t(ws_bytes),
+                C.c_int(1 if keep else 0), _lib.raw_stream(dev))
+        else:
+            filt = _c32(act[0])
+            acts = [torch.empty_like(t) for t in (sc_, rot_, op_)]
+            rc = L.ed3dgs_deform_forward_activated(
+                C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(xyz_), _ptr(sc_), _ptr(rot_), _ptr(op_),
+                _ptr(sh_), _ptr(shr_), *[_ptr(t) for t in outs], *[_ptr(t) for t in subs], _ptr(filt), *[_ptr(t) for t in acts],
+                _ptr(ws), C.c_size_t(ws_bytes), C.c_int(1 if keep else 0), _lib.raw_stream(dev))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         ctx.kept_ws = ws if rc == 1 else None
         ctx.cfgd = cfgd
         ctx.want_sub = want_sub
-        ctx.save_for_backward(table_, offsets_, fc, ff, emb_)
+        ctx.act = act is not None
+        saved = [table_, offsets_, fc, ff, emb_]
+        if ctx.act:   # the activation backward needs the raw final values (and the filter)
+            saved += [outs[1], outs[2], outs[3]] + ([filt] if filt is not None else [])
+        ctx.save_for_backward(*saved)
         ctx.shapes = [t.shape for t in (table, offsets, flat_c, flat_f, emb, xyz, scales, rot, opacity, sh)]
         ctx.split_sh = None if sh_rest is None else (sh.shape, sh_rest.shape)
-        if want_sub:
-            return tuple(outs) + tuple(subs)
-        return tuple(outs)
+        return tuple(outs) + (tuple(subs) if want_sub else ()) + tuple(acts)
 
     @staticmethod
     def backward(ctx, *gr):
@@ -79,10 +92,17 @@ class _DeformFn(torch.autograd.Function):
         cfg = _lib.DeformCfg(**{k: v for k, v in cfgd.items() if k != "use_stage" and k != "n_rows"})
         cfg.use_stage[0], cfg.use_stage[1] = cfgd["use_stage"]
         cfg.n_rows[0], cfg.n_rows[1] = cfgd["n_rows"]
-        table_, offsets_, fc, ff, emb_ = ctx.saved_tensors
+        table_, offsets_, fc, ff, emb_ = ctx.saved_tensors[:5]
         dev = emb_.device
         g_out = [_c32(g) for g in gr[:5]]
         g_sub = [_c32(g) for g in gr[5:10]] if ctx.want_sub else [None] * 5
+        g_act = raw = filt = g_raw = None
+        if ctx.act:
+            n0 = 10 if ctx.want_sub else 5
+            g_act = [_c32(g) for g in gr[n0:n0 + 3]]
+            raw = list(ctx.saved_tensors[5:8])
+            filt = ctx.saved_tensors[8] if len(ctx.saved_tensors) > 8 else None
+            g_raw = [torch.empty_like(t) for t in raw]   # dL/d(raw final scales / rotations / opacity), from the C call
         gfc = torch.empty_like(fc)
         gff = torch.empty_like(ff)
         g_table = torch.empty_like(table_)
@@ -101,10 +121,29 @@ class _DeformFn(torch.autograd.Function):
             ctx.kept_ws = None   # 6 KB per Gaussian go back to the allocator; a second backward (retain_graph) re-forms the activations
         params = (C.c_void_p * 2)(fc.data_ptr() if cfgd["use_stage"][0] else None, ff.data_ptr() if cfgd["use_stage"][1] else None)
         gparams = (C.c_void_p * 2)(gfc.data_ptr() if cfgd["use_stage"][0] else None, gff.data_ptr() if cfgd["use_stage"][1] else None)
-        rc = L.ed3dgs_deform_backward(
-            C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), *[_ptr(g) for g in g_out],
-            *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(g_dc), _ptr(g_rest), _ptr(ws),
-            C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), _lib.raw_stream(dev))
+        if not ctx.act:
+            rc = L.ed3dgs_deform_backward(
+                C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), *[_ptr(g) for g in g_out],
+                *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(g_dc), _ptr(g_rest), _ptr(ws),
+                C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), _lib.raw_stream(dev))
+        elif any(g is not None for g in g_out[1:4]):
+            # the caller ALSO differentiated through the raw final scales / rotations / opacity: convert the activated-space
+            # gradients with the stand-alone launch, add, and take the plain backward
+            z = lambda g, like: torch.zeros_like(like) if g is None else g
+            rc = L.ed3dgs_activations_backward(C.c_int(raw[0].shape[0]), _ptr(raw[0]), _ptr(raw[1]), _ptr(raw[2]), _ptr(filt),
+                                               *[_ptr(g) for g in g_act], *[_ptr(g) for g in g_raw], _lib.raw_stream(dev))
+            if rc >= 0:
+                g_raw = [a + z(b, a) for a, b in zip(g_raw, g_out[1:4])]
+                rc = L.ed3dgs_deform_backward(
+                    C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(g_out[0]), *[_ptr(g) for g in g_raw],
+                    _ptr(g_out[4]), *[_ptr(g) for g in g_sub], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(g_dc),
+                    _ptr(g_rest), _ptr(ws), C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), _lib.raw_stream(dev))
+        else:
+            rc = L.ed3dgs_deform_backward_activated(
+                C.byref(cfg), _ptr(table_), _ptr(offsets_), params, _ptr(emb_), _ptr(g_out[0]), _ptr(g_out[4]),
+                *[_ptr(g) for g in g_sub], *[_ptr(t) for t in raw], _ptr(filt), *[_ptr(g) for g in g_act],
+                *[_ptr(g) for g in g_raw], gparams, _ptr(g_table), _ptr(g_off), _ptr(g_emb), _ptr(g_dc), _ptr(g_rest), _ptr(ws),
+                C.c_size_t(ws_bytes), C.c_int(1 if kept else 0), _lib.raw_stream(dev))
         if rc < 0:
             raise RuntimeError(_lib.last_error())
         if not cfgd["use_stage"][0]:
@@ -114,6 +153,8 @@ class _DeformFn(torch.autograd.Function):
         base = []
         for i in range(4 if ctx.split_sh is not None else 5):  # identity paths: out = base + ..., sub = base + ...
             a, b = gr[i], (gr[5 + i] if ctx.want_sub else None)
+            if ctx.act and 1 <= i <= 3:
+                a = g_raw[i - 1]   # dL/d(raw final value), the activation backward included (plus gr[i] where that was given)
             g = a if b is None else (b if a is None else a + b)
             base.append(None if g is None else g.reshape(ctx.shapes[5 + i]))
         if ctx.split_sh is not None:
@@ -121,7 +162,7 @@ class _DeformFn(torch.autograd.Function):
         else:
             base.append(None)
         sh = ctx.shapes
-        return (None, None, None, g_table.reshape(sh[0]), g_off.reshape(sh[1]), gfc.reshape(sh[2]), gff.reshape(sh[3]),
+        return (None, None, None, None, g_table.reshape(sh[0]), g_off.reshape(sh[1]), gfc.reshape(sh[2]), gff.reshape(sh[3]),
                 g_emb.reshape(sh[4]), *base)
 
 
@@ -262,12 +303,16 @@ class deform_network(nn.Module):
 
     def forward(self, point, scales=None, rotations=None, opacity=None, time_emb=None, cam_no=None, pc=None,
                 embeddings=None, sh_coefs=None, iter=None, num_down_emb_c=30, num_down_emb_f=30, want_extras=True,
-                sh_coefs_rest=None):
+                sh_coefs_rest=None, activated=None):
         """The reference's signature (:108-141) plus two keywords.  `sh_coefs_rest`: pass the model's split SH storage
         as it is -- sh_coefs = _features_dc [P,1,3], sh_coefs_rest = _features_rest [P,n_sh-1,3] -- instead of their
         concatenation (get_features, scene/gaussian_model.py:128-131): the kernels read both and the backward writes both
         gradients, so neither the concatenation nor autograd's two slice copies run.  The last element of the returned
-        `orig` tuple is then the pair (sh_coefs, sh_coefs_rest)."""
+        `orig` tuple is then the pair (sh_coefs, sh_coefs_rest).
+        `activated`: None (the reference's behaviour: raw values), or a 1-tuple (filter_3D or None,): the returned scales /
+        rotations / opacity are then the ACTIVATED ones render() feeds the rasterizer (gaussian_renderer/__init__.py:77-83:
+        exp / F.normalize / sigmoid, or the 3D-filter variant of scene/gaussian_model.py:594-603), written by the MLP kernel
+        itself; the raw finals still exist inside the autograd node for the backward."""
         a = self.args
         pts, scales, rotations, opacity = point[:, :3], scales[:, :3], rotations[:, :4], opacity[:, :1]
         orig = (pts, scales, rotations, opacity, sh_coefs if sh_coefs_rest is None else (sh_coefs, sh_coefs_rest))
@@ -287,10 +332,16 @@ class deform_network(nn.Module):
                 opacity, sh_coefs, sh_coefs_rest)
         # decided here: inside autograd.Function.forward grad mode is off
         keep = KEEP_ACTIVATIONS and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args)
-        res = _DeformFn.apply(cfgd, bool(want_extras), bool(keep), *args)
+        res = _DeformFn.apply(cfgd, bool(want_extras), bool(keep), None if activated is None else tuple(activated), *args)
         final = res[:5]
         sub = res[5:10] if want_extras else orig
+        if activated is not None:
+            acts = res[-3:]
+            return final[0], acts[0], acts[1], acts[2], final[4], (tuple(sub), orig)
         return final[0], final[1], final[2], final[3], final[4], (tuple(sub), orig)
+
+
+    supports_activated = True   # render() may ask for the activated outputs (a reference deform_network has no such attribute)
 
 
 def initialize_weights(m):

@@ -319,6 +319,35 @@ int ed3dgs_deform_backward(const ed3dgs_deform_cfg *cfg, const float *table, con
                            float *const gparams[2], float *g_table, float *g_offsets, float *g_embedding,
                            float *g_base_sh_dc, float *g_base_sh_rest, char *workspace, size_t workspace_bytes, int activations_kept, void *stream);
 
+/*
+ * The same two calls with render()'s activations (gaussian_renderer/__init__.py:77-83; scene/gaussian_model.py:37-45, 594-603)
+ * folded in, so that the deformation emits the rasterizer's inputs directly and two launches per
+ * training step disappear:
+ *   act_rot = out_rot / max(|out_rot|, 1e-12), act_scales = exp(out_scales), act_opacity = sigmoid(out_opacity), or -- with
+ *   filter_3D [P,1] -- the 3D-filter variant of scene/gaussian_model.py:594-603.
+ * Forward: out_* (raw) are written as before -- the backward needs them -- and act_* [P,3] / [P,4] / [P,1] beside them.  Without a
+ * filter the fused MFMA kernels write act_* in their epilogue; with one (opacity then depends on the final scales), and on the
+ * layer-by-layer path, the library launches the stand-alone activation kernel behind the network on the same stream.
+ * Backward: ga_* = dL/d(act_*) (NULL = zero) replace g_scales / g_rot / g_opacity; raw_* are the forward's out_scales / out_rot /
+ * out_opacity; g_raw_* receive dL/d(out_*) for EVERY Gaussian (the caller adds them to the base tensors' gradients, identity
+ * paths).  In the default configuration the conversion runs inside the pass that reads the upstream gradients anyway.
+ */
+int ed3dgs_deform_forward_activated(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                                    const float *const params[2], const float *embedding, const float *xyz,
+                                    const float *scales, const float *rot, const float *opacity, const float *sh,
+                                    const float *sh_rest, float *out_xyz, float *out_scales, float *out_rot, float *out_opacity,
+                                    float *out_sh, float *sub_xyz, float *sub_scales, float *sub_rot, float *sub_opacity,
+                                    float *sub_sh, const float *filter_3D, float *act_scales, float *act_rot, float *act_opacity,
+                                    char *workspace, size_t workspace_bytes, int keep_activations, void *stream);
+int ed3dgs_deform_backward_activated(const ed3dgs_deform_cfg *cfg, const float *table, const float *offsets,
+                                     const float *const params[2], const float *embedding, const float *g_xyz, const float *g_sh,
+                                     const float *gs_xyz, const float *gs_scales, const float *gs_rot, const float *gs_opacity,
+                                     const float *gs_sh, const float *raw_scales, const float *raw_rot, const float *raw_opacity,
+                                     const float *filter_3D, const float *ga_scales, const float *ga_rot, const float *ga_opacity,
+                                     float *g_raw_scales, float *g_raw_rot, float *g_raw_opacity, float *const gparams[2],
+                                     float *g_table, float *g_offsets, float *g_embedding, float *g_base_sh_dc, float *g_base_sh_rest,
+                                     char *workspace, size_t workspace_bytes, int activations_kept, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

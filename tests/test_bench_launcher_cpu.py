@@ -43,6 +43,31 @@ def test_20_steps_of_c3_visit_every_camera_on_every_rank_count():
         assert len(set(d["rank0_items_timed"])) == 20
 
 
+import pytest
+
+
+@pytest.mark.parametrize("workload", ["C3", "C4", "C5"])
+def test_eight_rank_rehearsal_of_the_scaling_run(workload):
+    """what the driver's N = 8 run does around the step, on 8 gloo ranks (the shard of train.py:171-187's view loop,
+    /root/reference/train.py:134-187): equal item counts, every camera among each rank's 20 timed items, eight per-rank medians
+    in the one line rank 0 prints, exit code 0 after destroy_process_group()."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    ncam = importlib.import_module("bench").WORKLOADS[workload]["cams"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "0",
+                        "--workload", workload, "--rehearse-launcher"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["gpus_arg"] == 8 and d["launched_by_bench"] is True and d["backend"] == "gloo"
+    assert d["items_per_rank"] == [20.0] * 8 and d["last_step_ranks_counted"] == 8.0
+    assert len(d["step_ms_median_per_rank"]) == 8 and len(d["mean_num_rendered_per_rank"]) == 8
+    assert d["cameras_timed_per_rank"] == [float(ncam)] * 8, d["cameras_timed_per_rank"]
+    assert len(set(d["rank0_items_timed"])) == 20 and d["rank0_cameras_timed"] == list(range(ncam))
+    assert d["value"] is None and d["rehearsal"] is True
+
+
 def test_gpus_must_match_the_torchrun_world():
     env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",

@@ -399,3 +399,70 @@ def test_non_fp32_parameters_are_refused():
     with pytest.raises(TypeError, match="fp32"):
         net(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 4).cuda(), torch.zeros(4, 1).cuda(),
             0.5, None, _PC(torch.zeros(4, 32).cuda()), None, torch.zeros(4, 16, 3).cuda(), iter=10)
+
+
+@pytest.mark.parametrize("P,D,flags,with_filter", [
+    (5000, 1, {}, False), (65836, 1, {}, False), (5000, 1, {}, True), (5000, 1, dict(f32=True), False), (5000, 1, dict(dense=True), False),
+    (777, 1, dict(stateless=True), False), (3000, 2, {}, False), (5000, 1, dict(no_ds=True, no_dr=True), False),
+    (5000, 1, dict(no_fine_deform=True), False)],
+    ids=["5k", "tail-units", "filter3d", "fp32-mfma", "dense-walk", "stateless", "depth2", "no_ds-no_dr", "coarse-only"])
+def test_activations_inside_the_deformation_match_the_stand_alone_launch(P, D, flags, with_filter, monkeypatch, libopt):
+    """forward(..., activated=(filter,)) -- the MLP kernel's epilogue writes exp / normalize / sigmoid of the final values and the
+    activation backward runs inside the deformation backward's first pass (ed3dgs_deform_forward_activated / _backward_activated)
+    -- against forward(...) followed by the fused activation launch (ed3dgs_amd.activations, itself held to torch in
+    test_fused_activations_match_torch): same values bit for bit (one activation_math.h), base-tensor / embedding gradients equal,
+    parameter gradients equal up to the order of the atomic sums.  Covers the tail units (P = 65 836), the 3D-filter variant and
+    the configurations that take the stand-alone launch inside the library (fp32-MFMA kernels: in-kernel too; dense walk,
+    stateless, defor_depth 2: behind the network)."""
+    _need_gpu()
+    from oracle import deformation_ref as R
+    import scene.deformation as SD
+    from ed3dgs_amd.activations import fused_activations
+    from scene.deformation import deform_network
+    flags = dict(flags)
+    if flags.pop("f32", False):
+        libopt("DEFORM_FP32_MFMA", 1)
+    if flags.pop("dense", False):
+        libopt("DEFORM_DENSE_BWD", 1)
+    monkeypatch.setattr(SD, "KEEP_ACTIVATIONS", not flags.pop("stateless", False))
+    a = R.Args(**{**dict(no_do=False, use_coarse_temporal_embedding=True, c2f_temporal_iter=10000, deform_from_iter=5000), **flags})
+    torch.manual_seed(21)
+    W = 128 if D == 1 else 64
+    net = deform_network(D=D, W=W, min_embeddings=30, max_embeddings=150, num_frames=300, args=a).cuda()
+    with torch.no_grad():
+        net.weight.mul_(100.0)
+    g = torch.Generator().manual_seed(22)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+    base = dict(xyz=mk(P, 3), scales=mk(P, 3, sc=0.3) - 4, rot=mk(P, 4), opacity=mk(P, 1), dc=mk(P, 1, 3), rest=mk(P, 15, 3, sc=0.2),
+                emb=mk(P, 32, sc=0.1))
+    filt = (torch.rand(P, 1, generator=g) * 0.02).cuda() if with_filter else None
+    ws = [mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 1), mk(P, 16, 3)]
+    ws_sub = [mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 1), mk(P, 16, 3)]
+    dead = (torch.rand(P, generator=g) < 0.5).cuda()
+    for w in ws + ws_sub:
+        w[dead] = 0
+
+    def run(inside):
+        net.zero_grad(set_to_none=True)
+        b = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        kw = dict(activated=(filt,)) if inside else {}
+        outs = net(b["xyz"], b["scales"], b["rot"], b["opacity"], 0.37, None, _PC(b["emb"]), None, b["dc"], iter=20000,
+                   num_down_emb_c=30, num_down_emb_f=30, sh_coefs_rest=b["rest"], **kw)
+        fin, sub = list(outs[:5]), outs[5][0]
+        if not inside:
+            fin[1], fin[2], fin[3] = fused_activations(fin[1], fin[2], fin[3], filt)
+        loss = sum((x * w).sum() for x, w in zip(fin, ws)) + sum((x * w).sum() for x, w in zip(sub, ws_sub))
+        loss.backward()
+        return ([x.detach().clone() for x in fin + list(sub)], {k: v.grad.clone() for k, v in b.items()},
+                {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+
+    o1, g1, p1 = run(False)
+    o2, g2, p2 = run(True)
+    for i, (x, y) in enumerate(zip(o1, o2)):
+        assert torch.equal(x, y), i
+    assert float((o2[2].norm(dim=1) - 1).abs().max()) < 1e-5 and float(o2[1].min()) > 0 and 0 < float(o2[3].min()) and float(o2[3].max()) < 1
+    for k in g1:
+        assert float((g1[k] - g2[k]).abs().max()) <= 1e-6 * max(float(g1[k].abs().max()), 1e-30), k
+    assert float(g2["scales"][dead].abs().max()) == 0.0 and float(g2["scales"][~dead].abs().max()) > 0
+    for n in p1:
+        assert float((p1[n] - p2[n]).abs().max()) <= 1e-5 * max(float(p1[n].abs().max()), 1e-30), n

@@ -174,6 +174,23 @@ def test_strided_visit_covers_all_cameras():
             assert sorted(D.strided_item(mine, k) for k in range(len(mine))) == mine  # a permutation of the shard
 
 
+def test_visit_order_sees_every_camera_in_any_run_of_as_many_steps():
+    """bench.py's item schedule (dist.visit_order): a permutation of the shard, cameras round-robin -- C3 (8 x 50), C4 (15 x 300:
+    a single stride over the flat shard left two cameras out of 20 steps on four of eight ranks), C5 (8 x 150)."""
+    sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
+    from ed3dgs_amd import dist as D
+    for cams, frames in ((8, 50), (15, 300), (8, 150)):
+        for world in (1, 2, 4, 8):
+            for rank in range(world):
+                mine = D.shard_items(cams * frames, rank, world)
+                order = D.visit_order(mine, cams, frames)
+                assert sorted(order) == mine
+                for start in (0, 7, 100):
+                    run = [D.visit_item(mine, start + k, cams, frames) for k in range(cams)]
+                    assert {D.item_of(i, cams, frames)[0] for i in run} == set(range(cams)), (cams, world, rank, start)
+                assert len({D.visit_item(mine, k, cams, frames) for k in range(20)}) == 20
+
+
 def test_item_mapping_is_bijective():
     sys.path.insert(0, os.path.join(ROOT, "e-d3dgs_amd"))
     from ed3dgs_amd import dist as D
