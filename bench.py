@@ -73,7 +73,7 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     ups_color_flat = grads["color"].reshape(-1).contiguous()
     from ed3dgs_amd import _lib
     L = _lib.lib()
-    stats_acc = torch.zeros(4, device=device)
+    stats_acc = torch.zeros(272, device=device)   # ED3DGS_STATS_ACC_FLOATS (include/ed3dgs.h)
     stats_out = [torch.zeros(3, device=device), torch.zeros(3, device=device)]
     # opt-in: data-parallel training -- buckets all-reduced from autograd hooks as their gradients land
     reducer = D.BucketedGradReducer(params) if dp_grads else None

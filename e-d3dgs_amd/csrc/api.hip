@@ -70,15 +70,12 @@ GeometryState GeometryState::from_chunk(char *&chunk, size_t P)
     obtain(chunk, g.offsets_sorted, P, 128);
     g.sort_size = sort_temp_bytes((int)P);
     obtain(chunk, g.sort_space, g.sort_size, 128);
-    // the hand-written depth sort's buffers (binning.hip; opt-in, measured slower than the library's sort): LAST in the layout and
-    // carved only while the switch is on, so the default forward does not carry their 16 B per Gaussian + 48 KB, and everything a
-    // backward or a state view reads sits at the same offset either way
-    g.sort_a = g.sort_b = g.sort_counts = g.sort_params = nullptr;
-    if (opt(OPT_SORT_HANDWRITTEN)) {
+    // the hand-written depth sort's buffers (binning.hip): LAST in the layout and carved only when that sort runs, so that
+    // everything a backward or a state view reads sits at the same offset whichever sort the forward used
+    g.sort_a = g.sort_counts = nullptr;
+    if (depth_sort_handwritten((int)P)) {
         obtain(chunk, g.sort_a, 2 * P, 128);
-        obtain(chunk, g.sort_b, 2 * P, 128);
         obtain(chunk, g.sort_counts, depth_sort_count_words((int)P), 128);
-        obtain(chunk, g.sort_params, 32, 128);
     }
     return g;
 }
@@ -236,10 +233,12 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
         if (!check_hip(hipMemcpyAsync(rb.host, geom.block_tiles, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered")) return ED3DGS_ERR_HIP;
         if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     }
-    // binning level 1: the Gaussians by depth.  The library's sort (rocPRIM merge sort below a million keys: 9 launches, 60-70 us
-    // at 200k) stays the default: the hand-written three-pass radix sort (binning.hip, ED3DGS_SORT_HANDWRITTEN=1) is bit-identical
-    // and takes 6 launches but 80 us -- measured in round 3
-    if (!opt(OPT_SORT_HANDWRITTEN) || P > (1 << 20)) {
+    // binning level 1: the Gaussians by depth.  The library's stable sort (rocPRIM merge sort below a million keys: 9 launches, 61 us
+    // at 200k) is the default; ED3DGS_SORT_HANDWRITTEN=1 runs the bucket + rank sort of binning.hip instead (3 launches, 55 us,
+    // bit-identical order).  Round 4 measured why neither a faster sort nor fewer launches moves the step: the host needs the
+    // ~60 us this sort takes to receive K1's count, allocate the binning state and enqueue level 2 -- with the shorter sort the
+    // stream runs dry in front of bin2_countA instead.
+    if (!depth_sort_handwritten(P)) {
         if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     } else if (!launch_depth_sort(geom, P, s)) return ED3DGS_ERR_HIP;
     // level 2: the stable transpose (preprocess.hip) when the tile counters fit in LDS, else K3 + radix sort + K5
@@ -621,6 +620,7 @@ int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geome
                   !check_hip(hipDeviceSynchronize(), "point offsets scan"))) return ED3DGS_ERR_HIP;
     out->ranges = img.ranges; out->n_contrib = img.n_contrib; out->accum_coord = img.accum_coord;
     out->accum_depth = img.accum_depth; out->normal_length = img.normal_length;
+    out->depth_order = g.order;
     if (binning_buffer) {
         char *bc = const_cast<char *>(binning_buffer);
         BinningState b = BinningState::from_chunk(bc, R);

@@ -63,48 +63,51 @@ bool run_sort(char *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout
 
 
 // ------------------------------------------------------------------------------------------------------------
-// Binning level 1, hand-written: order[] = the P Gaussians sorted by their 32 depth bits, ties in id order
-// (CR/rasterizer_impl.cu:381-386 sorts (tile | depth) keys; the depth half is this sort, see the header of this file).
+// Binning level 1, hand-written (round 4): order[] = the P Gaussians sorted by their 32 depth bits, ties in id order, culled ones
+// (key 0xFFFFFFFF: they emit no instance) last, in id order -- the permutation a stable sort of (key, id) pairs leaves, which is
+// what CR/rasterizer_impl.cu:381-386 does to the depth half of its (tile | depth) keys (see the header of this file).
 //
-// A stable LSD radix sort in three passes over only the bits in which the frame's keys differ: K1 leaves the smallest and the
-// largest key of each of its blocks; k' = key - kmin needs nb = bitlength(kmax - kmin + 1) bits (24 .. 27 for scenes whose depth
-// spans 2 .. 16 binades) and the culled Gaussians (key 0xFFFFFFFF, they emit no instance) take the one value above the largest:
-// three digits of w = ceil(nb / 3) <= 11 bits.  Per pass two launches:
-//   count    tile (4096 keys) x digit histogram in LDS -> counts[pass][tile][digit];
-//   scatter  every block sums the count columns for itself (where its tile's keys of each digit start: the digit's start +
-//            the earlier tiles' keys of that digit; <= 49 x 2^w words at 200k -- a scan launch of its own would be one block's
-//            chain of loads), ranks its keys -- a wave at a time, a row of 64 keys at a time: the lanes holding the same digit
-//            are found with w ballots, their rank is a popcount, the row's count goes to the wave's running counter by ONE
-//            LDS atomic whose returned value is broadcast to them (no atomic's order decides a position) -- and writes
-//            (key, id) to its place.  Waves, rows and lanes are walked in order: the pass is stable.
-// 6 launches.  MEASURED (round 3, 200k keys): count 6-7 us, scatter 18-22 us per pass, 81 us in all -- SLOWER than the library's
-// merge sort behind hipcub::DeviceRadixSort (9 launches, 60-70 us; its Onesweep radix sort, forced: 15 launches, 155 us): 49
-// tiles occupy 49 of 256 CUs, and a scatter block is five dependent phases (frame extremes, column sums, key loads, 16 ranked
-// rows, scattered stores) of one or two memory / LDS-atomic latencies each.  It therefore stays OPT-IN (ED3DGS_SORT_HANDWRITTEN=1;
-// bit-identical lists: tests/test_binning_stress_gpu.py); what would beat the library is a single launch per pass with a
-// decoupled look-back instead of count + column sums, not attempted.
+// A stable sort of pairs whose input is in id order IS the sort by the 64-bit composite (key, id), and composites are distinct, so
+// the output is determined without any notion of stability -- which frees the algorithm from the pass structure of a radix sort
+// (rounds 2-3: the library's merge sort 9 launches / 60 us; its Onesweep 15 / 155; two hand-written sorts 6 / 81 and 3 / 86):
+//   1  depth_rank_count_kernel    every block finds the frame's smallest / largest key from K1's per-block extremes, maps a key to
+//                                 one of NB = 8192 buckets of equal width in KEY-BIT space ((key - kmin) >> shift; key bits of a
+//                                 positive float grow like its logarithm, so an outlier in depth costs buckets, not balance) and
+//                                 counts with one global atomic per key; culled keys are counted per block of ids; the block
+//                                 that finishes last scans the counts into bucket offsets (and the culled counts into a prefix);
+//   2  depth_rank_scatter_kernel  drops each (key, id) into its bucket at the next free slot -- a returning atomic on the
+//                                 bucket's cursor: the order INSIDE a bucket is whatever the atomics made it; culled ids go
+//                                 straight to their final places behind the visible ones;
+//   3  depth_rank_place_kernel    thread = slot: the composite's rank inside its bucket is the number of smaller composites in
+//                                 it (the block's few hundred neighbouring pairs staged in LDS), and order[bucket start + rank]
+//                                 = id.  Deterministic whatever order step 2's atomics produced.
+// Cost is linear in P while buckets stay small; a bucket of m pairs costs m^2 compares, so a frame whose depths pile into few
+// buckets (many equal depths) degrades gracefully -- 4096 pairs in one bucket are 16 M compares, still microseconds -- and stays
+// correct at any size.  counts / cursors / ticket (2 x 32 KB + 256 B) are zeroed by K1's first blocks (the launch in front of step 1).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int DS_TILE = 4096, DS_IPT = 16, DS_MAXBINS = 2048;
+constexpr int DR_NB = 8192, DR_IPT = 2, DR_TILE = 256 * DR_IPT;
+// sort_counts layout (words): counts [NB] | cursors [NB] | ticket + pad [64] -- those zeroed by K1 -- | offs [NB + 1], n_vis = offs[NB],
+// kmin, shift [NB + 64 in all] | culled ids per block [nblk] | their exclusive prefix [nblk]
+constexpr int DR_TICKET = 2 * DR_NB, DR_OFFS = 2 * DR_NB + 64, DR_BLK = DR_OFFS + DR_NB + 64;
+static_assert(DR_TICKET + 64 == DEPTH_SORT_ZERO_WORDS, "K1 zeroes counts, cursors and the ticket");
 
 size_t depth_sort_count_words(int P)
 {
-    const size_t tiles = ((size_t)(P > 0 ? P : 0) + DS_TILE - 1) / DS_TILE + 1;
-    return 3 * tiles * DS_MAXBINS;
+    const size_t nblk = ((size_t)(P > 0 ? P : 0) + DR_TILE - 1) / DR_TILE + 1;
+    return (size_t)DR_BLK + 2 * nblk + 64;
 }
 
-struct DepthSort {
-    int P, ntiles, nblk_k1, pass;
-    const uint32_t *raw;            // K1's keys (pass 0 reads them and forms k')
-    const uint32_t *block_kminmax;
-    const uint32_t *in;             // [2][P] (k', id) of the previous pass
-    uint32_t *out;                  // [2][P]; the last pass writes the ids to `order` instead
+struct DepthRank {
+    int P, nblk_k1, nblk;
+    const uint32_t *keys;            // K1's depth bits (0xFFFFFFFF: culled)
+    const uint32_t *block_kminmax;   // K1's per-block smallest / largest visible key
+    uint32_t *w;                     // sort_counts (layout above)
+    uint2 *pairs;                    // [P] (key, id), bucket by bucket
     uint32_t *order;
-    uint32_t *counts;               // this pass's [ntiles][bins]
-    uint32_t *params;
 };
 
-// {kmin, nb, w} of the frame from K1's per-block extremes, by every block for itself (a few hundred words)
-__device__ __forceinline__ void depth_sort_params(const DepthSort &a, uint32_t *sh, uint32_t &kmin, uint32_t &culled_key, int &w)
+// {kmin, shift} of the frame from K1's per-block extremes, by every block of step 1 for itself (a few hundred words from L2)
+__device__ __forceinline__ void depth_rank_params(const DepthRank &a, uint32_t *sh, uint32_t &kmin, int &shift)
 {
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
     for (int b = threadIdx.x; b < a.nblk_k1; b += blockDim.x) { mn = min(mn, a.block_kminmax[2 * b]); mx = max(mx, a.block_kminmax[2 * b + 1]); }
@@ -116,100 +119,55 @@ __device__ __forceinline__ void depth_sort_params(const DepthSort &a, uint32_t *
     __syncthreads();
     if (mn > mx) { mn = 0u; mx = 0u; }                 // no visible Gaussian at all
     kmin = mn;
-    culled_key = mx - mn + 1u;                          // one above the largest k'
-    const int bits = culled_key ? 32 - __builtin_clz(culled_key) : 32;   // the values 0 .. culled_key (0: the span wrapped, all 32)
-    w = (bits + 2) / 3;
-    if (w < 1) w = 1;
+    const uint32_t span = mx - mn;                     // bucket = (key - kmin) >> shift must stay below NB
+    const int bits = span ? 32 - __builtin_clz(span) : 0;
+    shift = max(0, bits - 13);                         // NB = 2^13
 }
 
-__global__ void __launch_bounds__(256) depth_sort_count_kernel(DepthSort a)
-{
-    __shared__ uint32_t hist[DS_MAXBINS];
-    __shared__ uint32_t red[8];
-    uint32_t kmin, culled;
-    int w;
-    depth_sort_params(a, red, kmin, culled, w);
-    const int bins = 1 << w, shift = a.pass * w;
-    for (int q = threadIdx.x; q < bins; q += 256) hist[q] = 0u;
-    __syncthreads();
-    const int base = blockIdx.x * DS_TILE;
-    uint32_t k[DS_IPT];
-#pragma unroll
-    for (int j = 0; j < DS_IPT; j++) {
-        const int i = base + j * 256 + threadIdx.x;
-        uint32_t v = 0xFFFFFFFFu;
-        if (i < a.P) v = a.pass == 0 ? a.raw[i] : a.in[i];
-        k[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < DS_IPT; j++) {
-        const int i = base + j * 256 + threadIdx.x;
-        if (i >= a.P) continue;
-        const uint32_t kp = a.pass == 0 ? (k[j] == 0xFFFFFFFFu ? culled : k[j] - kmin) : k[j];
-        atomicAdd(&hist[(kp >> shift) & (uint32_t)(bins - 1)], 1u);
-    }
-    __syncthreads();
-    uint32_t *row = a.counts + (size_t)blockIdx.x * bins;
-    for (int q = threadIdx.x; q < bins; q += 256) row[q] = hist[q];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.pass == 0) { a.params[0] = kmin; a.params[1] = culled; a.params[2] = (uint32_t)w; }
-}
+__device__ __forceinline__ uint32_t coherent_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ void __launch_bounds__(256) depth_sort_scatter_kernel(DepthSort a)
+// Step 1: bucket counts (one global atomic per visible key), culled ids per block; the block that takes the last ticket scans the
+// counts into bucket offsets and the per-block culled counts into their prefix, for steps 2 and 3.  Ordering without fences (a
+// device-scope release would write back the XCD's L2): everything the last block reads was written by RETURNING atomics whose
+// results their threads consumed before the block's barrier, and the ticket is taken behind that barrier (the idiom of
+// deform_active_rows_body and image_stats_kernel); the last block reads with agent-scope loads.
+__global__ void __launch_bounds__(256) depth_rank_count_kernel(DepthRank a)
 {
-    __shared__ uint32_t wcnt[4][DS_MAXBINS];   // per wave and digit: running count, then the position of the wave's first key
-    __shared__ uint32_t tot[DS_MAXBINS];       // per digit: keys of all tiles, then their exclusive scan
     __shared__ uint32_t red[8], wsum[4];
-    uint32_t kmin, culled;
-    int w;
-    depth_sort_params(a, red, kmin, culled, w);
-    const int bins = 1 << w, shift = a.pass * w;
+    __shared__ bool last_s;
+    uint32_t kmin;
+    int shift;
+    depth_rank_params(a, red, kmin, shift);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int q = tid; q < 4 * DS_MAXBINS; q += 256) (&wcnt[0][0])[q] = 0u;
-    // column sums: digits in groups of 8 (two 16-byte loads per tile row); the block's 256 threads split the tiles of a group
-    // among themselves and keep FOUR rows' loads in flight each (a thread walking all tiles of its group alone is a chain of
-    // ntiles memory latencies: 30 us per pass at 200k keys), partial sums meet in LDS
-    __shared__ uint32_t pre_s[DS_MAXBINS], all_s[DS_MAXBINS];
-    for (int q = tid; q < bins; q += 256) { pre_s[q] = 0u; all_s[q] = 0u; }
-    __syncthreads();
-    if (bins >= 8) {
-        const int ngrp = bins >> 3, parts = max(1, 256 / ngrp);
-        const int grp = tid % ngrp, part = tid / ngrp;
-        if (part < parts) {
-            uint32_t pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, aa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int t0 = part; t0 < a.ntiles; t0 += 4 * parts) {
-                uint4 lo[4], hi[4];
+    const int base = blockIdx.x * DR_TILE;
+    uint32_t k[DR_IPT];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int t = min(t0 + u * parts, a.ntiles - 1);
-                    lo[u] = *reinterpret_cast<const uint4 *>(a.counts + (size_t)t * bins + 8 * grp);
-                    hi[u] = *reinterpret_cast<const uint4 *>(a.counts + (size_t)t * bins + 8 * grp + 4);
-                }
+    for (int j = 0; j < DR_IPT; j++) { const int i = base + j * 256 + tid; k[j] = i < a.P ? a.keys[i] : 0u; }
+    uint32_t nc = 0, seen = 0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int t = t0 + u * parts;
-                    if (t >= a.ntiles) continue;
-                    const uint32_t v[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+    for (int j = 0; j < DR_IPT; j++) {
+        const int i = base + j * 256 + tid;
+        if (i >= a.P) continue;
+        if (k[j] == 0xFFFFFFFFu) nc++;
+        else seen += atomicAdd(&a.w[(k[j] - kmin) >> shift], 1u);   // RETURNING: consumed below, before the block's ticket
+    }
+    asm volatile("" :: "v"(seen) : "memory");   // the results are in registers here: the adds have been performed at the memory side
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { aa[q] += v[q]; pp[q] += t < (int)blockIdx.x ? v[q] : 0u; }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) { atomicAdd(&all_s[8 * grp + q], aa[q]); atomicAdd(&pre_s[8 * grp + q], pp[q]); }
-        }
-    } else if (tid == 0) {
-        for (int t = 0; t < a.ntiles; t++)
-            for (int q = 0; q < bins; q++) { const uint32_t v = a.counts[(size_t)t * bins + q]; all_s[q] += v; pre_s[q] += t < (int)blockIdx.x ? v : 0u; }
+    for (int o = 32; o > 0; o >>= 1) nc += (uint32_t)__shfl_xor((int)nc, o);
+    if (lane == 0) wsum[wave] = nc;
+    __syncthreads();   // every thread of the block is past its atomics' results
+    if (tid == 0) {
+        const uint32_t old = atomicExch(&a.w[DR_BLK + blockIdx.x], wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        asm volatile("" :: "v"(old) : "memory");        // its result is back: the exchange has been performed
+        last_s = atomicAdd(&a.w[DR_TICKET], 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    const int d0 = 8 * tid;
-    uint32_t pre[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!last_s) return;
+    // exclusive scan of the bucket counts: 32 consecutive buckets per thread, a wave scan, the four wave sums
+    constexpr int PER = DR_NB / 256;
+    uint32_t c[PER], mine = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++)
-        if (d0 + q < bins) { pre[q] = pre_s[d0 + q]; all[q] = all_s[d0 + q]; }
-    // exclusive scan of the digit totals over the block: 8 per thread, a wave scan, the four wave sums
-    uint32_t mine = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) mine += all[q];
+    for (int q = 0; q < PER; q++) { c[q] = coherent_load(&a.w[tid * PER + q]); mine += c[q]; }
     uint32_t inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = __shfl_up(inc, o); if (lane >= o) inc += nb; }
@@ -217,80 +175,120 @@ __global__ void __launch_bounds__(256) depth_sort_scatter_kernel(DepthSort a)
     __syncthreads();
     uint32_t run = inc - mine;
     for (int q = 0; q < wave; q++) run += wsum[q];
-    if (d0 < bins) {
+    const uint32_t n_vis = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (d0 + q < bins) tot[d0 + q] = run + pre[q];   // where THIS tile's keys of digit d0 + q start
-            run += all[q];
-        }
-    }
-    // the tile's keys: wave `wave` owns rows 16 wave .. 16 wave + 15 of 64 consecutive keys
-    const int base = blockIdx.x * DS_TILE + wave * (DS_IPT * 64);
-    uint32_t kp[DS_IPT], id[DS_IPT], rank[DS_IPT];
-#pragma unroll
-    for (int j = 0; j < DS_IPT; j++) {
-        const int i = base + j * 64 + lane;
-        const int ii = min(i, a.P - 1);
-        if (a.pass == 0) {
-            const uint32_t raw = a.raw[ii];
-            kp[j] = raw == 0xFFFFFFFFu ? culled : raw - kmin;
-            id[j] = (uint32_t)ii;
-        } else {
-            kp[j] = a.in[ii];
-            id[j] = a.in[(size_t)a.P + ii];
-        }
-    }
-    __syncthreads();   // wcnt zeroed, tot written
-#pragma unroll
-    for (int j = 0; j < DS_IPT; j++) {
-        const bool in = base + j * 64 + lane < a.P;
-        const uint32_t d = (kp[j] >> shift) & (uint32_t)(bins - 1);
-        unsigned long long m = __ballot(in);           // lanes of this row with the same digit
-        for (int b = 0; b < w; b++) {
-            const unsigned long long bal = __ballot((d >> b) & 1u);
-            m &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        if (!in) m = 0ull;
-        const int leader = m ? __builtin_ctzll(m) : 0;
-        uint32_t prior = 0;
-        if (in && lane == leader) prior = atomicAdd(&wcnt[wave][d], (uint32_t)__popcll(m));   // one LDS atomic per (row, digit)
-        prior = (uint32_t)__shfl((int)prior, leader);
-        rank[j] = prior + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
+    for (int q = 0; q < PER; q++) { a.w[DR_OFFS + tid * PER + q] = run; run += c[q]; }
+    if (tid == 0) { a.w[DR_OFFS + DR_NB] = n_vis; a.w[DR_OFFS + DR_NB + 1] = kmin; a.w[DR_OFFS + DR_NB + 2] = (uint32_t)shift; }
     __syncthreads();
-    // per digit: the waves' first positions (tile start of the digit + the lower waves' keys of it)
-    for (int d = tid; d < bins; d += 256) {
-        uint32_t r = tot[d];
+    // exclusive prefix of the per-block culled counts (blocks of DR_TILE ids)
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < a.nblk; b0 += 256) {
+        const int b = b0 + tid;
+        const uint32_t v = b < a.nblk ? coherent_load(&a.w[DR_BLK + b]) : 0u;
+        uint32_t pinc = v;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const uint32_t v = wcnt[q][d]; wcnt[q][d] = r; r += v; }
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t nb = __shfl_up(pinc, o); if (lane >= o) pinc += nb; }
+        if (lane == 63) wsum[wave] = pinc;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int q = 0; q < wave; q++) before += wsum[q];
+        if (b < a.nblk) a.w[DR_BLK + a.nblk + b] = before + pinc - v;
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
     }
+}
+
+// Step 2: every (key, id) into its bucket at the next free slot (a returning atomic on the bucket's cursor); culled ids to their
+// final places behind the visible ones, in id order
+__global__ void __launch_bounds__(256) depth_rank_scatter_kernel(DepthRank a)
+{
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *offs = a.w + DR_OFFS;
+    const uint32_t n_vis = offs[DR_NB], kmin = offs[DR_NB + 1];
+    const int shift = (int)offs[DR_NB + 2];
+    const int base = blockIdx.x * DR_TILE;
+    uint32_t k[DR_IPT], slot[DR_IPT], start[DR_IPT];
+#pragma unroll
+    for (int j = 0; j < DR_IPT; j++) { const int i = base + j * 256 + tid; k[j] = i < a.P ? a.keys[i] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (int j = 0; j < DR_IPT; j++) {   // a thread's returning atomics and offset loads are in flight together
+        const bool vis = k[j] != 0xFFFFFFFFu;
+        const uint32_t b = vis ? (k[j] - kmin) >> shift : 0u;
+        slot[j] = vis ? atomicAdd(&a.w[DR_NB + b], 1u) : 0u;
+        start[j] = offs[b];
+    }
+    uint32_t cull_run = n_vis + a.w[DR_BLK + a.nblk + blockIdx.x];   // ids ascend with (j, wave, lane): the culled ones keep that order
+#pragma unroll
+    for (int j = 0; j < DR_IPT; j++) {
+        const int i = base + j * 256 + tid;
+        const bool in = i < a.P, culled = in && k[j] == 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(culled);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int q = 0; q < wave; q++) before += wsum[q];
+        const uint32_t row_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (culled) a.order[cull_run + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        else if (in) a.pairs[start[j] + slot[j]] = make_uint2(k[j], (uint32_t)i);
+        cull_run += row_total;
+        __syncthreads();
+    }
+}
+
+// Step 3: thread = slot p of the bucketed array; rank of its composite inside its bucket = the number of smaller composites there;
+// order[bucket start + rank] = id.  The block's 256 slots and the buckets they fall in span a few hundred consecutive pairs: those
+// are staged in LDS once (coalesced) and ranked from there; a span too long for the buffer (a crowded bucket) is read from memory.
+constexpr int DR_SPAN = 1536;
+__global__ void __launch_bounds__(256) depth_rank_place_kernel(DepthRank a)
+{
+    __shared__ uint2 sp[DR_SPAN];
+    __shared__ uint32_t lo_s, hi_s;
+    const uint32_t *offs = a.w + DR_OFFS;
+    const uint32_t n_vis = offs[DR_NB], kmin = offs[DR_NB + 1];
+    const int shift = (int)offs[DR_NB + 2];
+    const uint32_t p0 = blockIdx.x * 256u;
+    if (p0 >= n_vis) return;
+    const uint32_t p = p0 + threadIdx.x;
+    const bool live = p < n_vis;
+    const uint2 me = a.pairs[live ? p : n_vis - 1];
+    const uint32_t b = (me.x - kmin) >> shift;
+    const uint32_t start = offs[b], end = offs[b + 1];
+    // slots ascend with the bucket: the block's span is [start of the first thread's bucket, end of the last live thread's)
+    const uint32_t last_live = min(255u, n_vis - 1u - p0);
+    if (threadIdx.x == 0) lo_s = start;
+    if (threadIdx.x == last_live) hi_s = end;
     __syncthreads();
-    const bool last = a.pass == 2;
-#pragma unroll
-    for (int j = 0; j < DS_IPT; j++) {
-        if (base + j * 64 + lane >= a.P) continue;
-        const uint32_t d = (kp[j] >> shift) & (uint32_t)(bins - 1);
-        const uint32_t pos = wcnt[wave][d] + rank[j];
-        if (last) a.order[pos] = id[j];
-        else { a.out[pos] = kp[j]; a.out[(size_t)a.P + pos] = id[j]; }
+    const uint32_t lo = lo_s, hi = hi_s;
+    uint32_t r = 0;
+    if (hi - lo <= (uint32_t)DR_SPAN) {
+        for (uint32_t q = lo + threadIdx.x; q < hi; q += 256u) sp[q - lo] = a.pairs[q];
+        __syncthreads();
+        if (live)
+            for (uint32_t j = start; j < end; j++) { const uint2 q = sp[j - lo]; r += (q.x < me.x || (q.x == me.x && q.y < me.y)); }
+    } else if (live) {
+        uint32_t j = start;
+        for (; j + 4 <= end; j += 4) {
+            const uint2 q0 = a.pairs[j], q1 = a.pairs[j + 1], q2 = a.pairs[j + 2], q3 = a.pairs[j + 3];
+            r += (q0.x < me.x || (q0.x == me.x && q0.y < me.y)) + (q1.x < me.x || (q1.x == me.x && q1.y < me.y)) +
+                 (q2.x < me.x || (q2.x == me.x && q2.y < me.y)) + (q3.x < me.x || (q3.x == me.x && q3.y < me.y));
+        }
+        for (; j < end; j++) { const uint2 q = a.pairs[j]; r += (q.x < me.x || (q.x == me.x && q.y < me.y)); }
     }
+    if (live) a.order[start + r] = me.y;
 }
 
 bool launch_depth_sort(const GeometryState &g, int P, hipStream_t s)
 {
     if (P <= 0) return true;
-    DepthSort a;
-    a.P = P; a.ntiles = (P + DS_TILE - 1) / DS_TILE; a.nblk_k1 = (P + 255) / 256;
-    a.raw = g.depth_keys; a.block_kminmax = g.block_kminmax; a.order = g.order; a.params = g.sort_params;
-    const size_t stride = (size_t)(a.ntiles + 1) * DS_MAXBINS;
-    for (int pass = 0; pass < 3; pass++) {
-        a.pass = pass;
-        a.in = pass == 1 ? g.sort_a : g.sort_b;     // pass 0 reads the raw keys
-        a.out = pass == 0 ? g.sort_a : g.sort_b;    // pass 2 writes `order`
-        a.counts = g.sort_counts + pass * stride;
-        hipLaunchKernelGGL(depth_sort_count_kernel, dim3(a.ntiles), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(depth_sort_scatter_kernel, dim3(a.ntiles), dim3(256), 0, s, a);
-    }
+    DepthRank a;
+    a.P = P; a.nblk_k1 = (P + 255) / 256; a.nblk = (P + DR_TILE - 1) / DR_TILE;
+    a.keys = g.depth_keys; a.block_kminmax = g.block_kminmax; a.order = g.order;
+    a.w = g.sort_counts;
+    a.pairs = reinterpret_cast<uint2 *>(g.sort_a);
+    hipLaunchKernelGGL(depth_rank_count_kernel, dim3(a.nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(depth_rank_scatter_kernel, dim3(a.nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(depth_rank_place_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a);
     return check_hip(hipGetLastError(), "depth sort");
 }
 

@@ -54,9 +54,8 @@ struct GeometryState {
     uint32_t *point_offsets;   // inclusive scan of tiles_touched in Gaussian order: formed on demand (ed3dgs_state_view_get) only
     uint32_t *block_tiles;     // [ceil(P / 256)] sum of tiles_touched over each preprocess block: the host adds them up (num_rendered)
     uint32_t *block_kminmax;   // [ceil(P / 256)][2] smallest / largest depth key of each preprocess block's visible Gaussians
-    uint32_t *sort_a, *sort_b; // [2][P] each: (key, id) ping-pong buffers of the depth sort (binning.hip)
-    uint32_t *sort_counts;     // [3][tiles][bins] per-tile digit counts of its three passes
-    uint32_t *sort_params;     // {kmin, bits, digit width}
+    uint32_t *sort_a;          // [P][2] (key, id) pairs of the depth sort, bucket by bucket (binning.hip); NULL with the library's sort
+    uint32_t *sort_counts;     // bucket counts | cursors | offsets | per-block culled counts (depth_sort_count_words)
     char *scan_space;
     size_t scan_size;
     // depth pre-sort (binning level 1): Gaussians ordered by view depth, and the scan of tiles_touched in THAT order
@@ -133,6 +132,8 @@ bool run_sort(char *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout
               int n, int end_bit, hipStream_t s);
 // binning level 1: order[] = the Gaussians by depth key (ties by id), hand-written (binning.hip)
 size_t depth_sort_count_words(int P);
+inline bool depth_sort_handwritten(int P) { return opt(OPT_SORT_HANDWRITTEN) && P <= (1 << 20); }   // else the library's sort (the default)
+constexpr int DEPTH_SORT_ZERO_WORDS = 2 * 8192 + 64;   // counts | cursors | ticket at the head of sort_counts: zero when the sort starts (K1 zeroes them)
 bool launch_depth_sort(const GeometryState &g, int P, hipStream_t s);
 
 void launch_render_forward(int W, int H, const uint32_t *ranges, const uint32_t *point_list, const float *rec,

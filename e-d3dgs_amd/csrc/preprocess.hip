@@ -202,9 +202,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float *__restrict__ rec, float *__restrict__ rec_coord, float *__restrict__ depths, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ depth_keys,
     uint32_t *__restrict__ ids, int gx, int gy, float *__restrict__ invraycov, uint8_t *__restrict__ condition,
-    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax, float *__restrict__ eig, CountMail mail)
+    uint32_t *__restrict__ block_tiles, uint32_t *__restrict__ block_kminmax, float *__restrict__ eig, CountMail mail,
+    uint32_t *__restrict__ zero_words, int n_zero)   // the depth sort's bucket counters (binning.hip), zeroed on the way: it starts behind this launch
 {
     const int idx_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = idx_raw; i < n_zero; i += gridDim.x * blockDim.x) zero_words[i] = 0u;
     const bool live = idx_raw < P;
     const int idx = live ? idx_raw : P - 1;
     // (Tried in round 2: the block's SH rows fetched as one coalesced stream into LDS and read from there -- 53 us instead of
@@ -998,13 +1000,13 @@ void launch_preprocess(int P, int D, int M, const float *means, const float *sca
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, invraycov, condition,
-                           g.block_tiles, g.block_kminmax, (float *)nullptr, mail);
+                           g.block_tiles, g.block_kminmax, (float *)nullptr, mail, g.sort_counts, g.sort_counts ? DEPTH_SORT_ZERO_WORDS : 0);
     else {
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means, scales,
                            scale_modifier, rotations, opacities, tongue, shs, cov3D_precomp, colors_precomp, view, proj,
                            campos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, radii, g.rec, g.rec_coord,
                            g.depths, g.cov3D, g.clamped, g.tiles_touched, g.depth_keys, g.ids, gx, gy, (float *)nullptr,
-                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax, g.eig, mail);
+                           (uint8_t *)nullptr, g.block_tiles, g.block_kminmax, g.eig, mail, g.sort_counts, g.sort_counts ? DEPTH_SORT_ZERO_WORDS : 0);
     }
 }
 

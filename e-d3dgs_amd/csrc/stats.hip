@@ -5,8 +5,11 @@
 
 namespace ed3 {
 
-// acc: [0] sum image*weight, [1] sum (image - mid)^2, [2] (as uint) blocks done.  Must be zero on entry; the last block to finish
-// writes out[3] = {loss, psnr, 1} and leaves acc zero again for the next call on the stream.
+// acc: STATS_SLOTS accumulator pairs, one 64-byte line each ([16 k] sum image*weight, [16 k + 1] sum (image - mid)^2 of the blocks
+// b = k mod STATS_SLOTS), then the ticket word at [16 STATS_SLOTS] (as uint: blocks done).  Must be zero on entry; the last block to
+// finish writes out[3] = {loss, psnr, 1} and leaves acc zero again for the next call on the stream.  (Round 4: one pair for all
+// blocks meant 3 x 256 atomics on ONE line, which serialise at ~26 ns each -- 20 us for a launch whose 50 MB stream in 10.)
+constexpr int STATS_SLOTS = 16;
 __global__ void __launch_bounds__(256) image_stats_kernel(const float *__restrict__ image, const float *__restrict__ weight, size_t n,
                                                           float mid, float *__restrict__ acc, float *__restrict__ out)
 {
@@ -37,19 +40,27 @@ __global__ void __launch_bounds__(256) image_stats_kernel(const float *__restric
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { part[0][wave] = s0; part[1][wave] = s1; }
     __syncthreads();
+    unsigned *ticket = reinterpret_cast<unsigned *>(acc + 16 * STATS_SLOTS);
     if (threadIdx.x == 0) {
         // RETURNING atomics, their results consumed before the ticket is taken: an atomic's result is back only once the add has
         // been performed at the memory side, so the ticket cannot overtake a sum (as deform_active_rows_body orders its
         // counters).  No fence: a device-scope release would write back the XCD's whole L2 -- the price of one per block -- and
         // nothing here is a plain store another block reads.
-        const float r0 = atomicAdd(acc + 0, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        const float r1 = atomicAdd(acc + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        float *slot = acc + 16 * (blockIdx.x % STATS_SLOTS);
+        const float r0 = atomicAdd(slot + 0, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        const float r1 = atomicAdd(slot + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
         asm volatile("" :: "v"(r0), "v"(r1) : "memory");   // both results are in registers here (s_waitcnt vmcnt(0) precedes this point)
-        const unsigned done = atomicAdd(reinterpret_cast<unsigned *>(acc + 2), 1u);
+        const unsigned done = atomicAdd(ticket, 1u);
         last = done == gridDim.x - 1;
-        if (last) {
-            const float a0 = atomicExch(acc + 0, 0.f), a1 = atomicExch(acc + 1, 0.f);
-            atomicExch(reinterpret_cast<unsigned *>(acc + 2), 0u);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {   // one wave gathers the slots (atomic exchanges: they read the memory-side values and re-arm the slots)
+        float a0 = 0.f, a1 = 0.f;
+        if (threadIdx.x < STATS_SLOTS) { a0 = atomicExch(acc + 16 * threadIdx.x, 0.f); a1 = atomicExch(acc + 16 * threadIdx.x + 1, 0.f); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+        if (threadIdx.x == 0) {
+            atomicExch(ticket, 0u);
             out[0] = a0;
             out[1] = -10.0f * log10f(a1 / (float)n);
             out[2] = 1.0f;
@@ -132,7 +143,7 @@ extern "C" int ed3dgs_image_stats(const float *image, const float *weight, size_
 {
     if (!image || !weight || !acc || !out3 || n == 0) { set_error("ed3dgs_image_stats: null pointer or empty image"); return ED3DGS_ERR_INVALID; }
     if (((uintptr_t)image | (uintptr_t)weight) & 15) { set_error("ed3dgs_image_stats: image / weight must be 16-byte aligned"); return ED3DGS_ERR_INVALID; }
-    const int blocks = (int)std::min<size_t>(opt(OPT_STATS_BLOCKS) > 0 ? opt(OPT_STATS_BLOCKS) : 256, (n / 4 + 1023) / 1024 + 1);   // few blocks: three same-line atomics per block serialise (512 blocks: 28 us, 256: 20 us)
+    const int blocks = (int)std::min<size_t>(opt(OPT_STATS_BLOCKS) > 0 ? opt(OPT_STATS_BLOCKS) : 256, (n / 4 + 1023) / 1024 + 1);   // (with ONE accumulator line: 512 blocks 28 us, 256 blocks 20 us)
     hipLaunchKernelGGL(image_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, weight, n, mid, acc, out3);
     return check_hip(hipGetLastError(), "image_stats") ? 0 : ED3DGS_ERR_HIP;
 }

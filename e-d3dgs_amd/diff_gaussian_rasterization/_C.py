@@ -272,7 +272,7 @@ def state_view(P, H, W, R, geomBuffer, binningBuffer, imageBuffer):
         rec_coord=view(g, sv.rec_coord, P * 12, np.float32).reshape(P, 12),
         depths=view(g, sv.depths, P, np.float32), cov3D=view(g, sv.cov3D, P * 6, np.float32).reshape(P, 6),
         clamped=view(g, sv.clamped, P, np.uint8), tiles_touched=view(g, sv.tiles_touched, P, np.uint32),
-        point_offsets=view(g, sv.point_offsets, P, np.uint32),
+        point_offsets=view(g, sv.point_offsets, P, np.uint32), depth_order=view(g, sv.depth_order, P, np.uint32),
         ranges=view(i, sv.ranges, T * 2, np.uint32).reshape(T, 2),
         n_contrib=view(i, sv.n_contrib, 2 * H * W, np.uint32).reshape(2, H, W),
         accum_coord=view(i, sv.accum_coord, 3 * H * W, np.float32).reshape(3, H, W),

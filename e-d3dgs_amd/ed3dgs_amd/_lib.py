@@ -24,7 +24,7 @@ class DeformCfg(C.Structure):
 class StateView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "rec", "rec_coord", "depths", "cov3D", "clamped", "tiles_touched", "point_offsets", "point_list_keys",
-        "point_list", "ranges", "n_contrib", "accum_coord", "accum_depth", "normal_length")]
+        "point_list", "ranges", "n_contrib", "accum_coord", "accum_depth", "normal_length", "depth_order")]
 
 
 def build(verbose=False):

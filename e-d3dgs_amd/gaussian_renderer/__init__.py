@@ -9,11 +9,16 @@ keys (:128-142), so train.py / render.py call them unchanged.  What differs is h
 `integrate` (mesh probing) is below; `render_old` (DGR-old) is outside the scope.
 """
 import math
+import os
 
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from ed3dgs_amd.activations import fused_activations
+
+
+# False: the activations as a launch of their own behind the deformation (round 3's form; A/B runs: ED3DGS_SEPARATE_ACTIVATIONS=1)
+FUSE_ACTIVATIONS = os.environ.get("ED3DGS_SEPARATE_ACTIVATIONS", "0") in ("", "0")
 
 
 def _standard_activations(pc):
@@ -100,7 +105,7 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
     # north_star "the deformation MLP fused with the preprocess": when the model's activations are the reference's own, the MLP
     # kernel's epilogue writes the rasterizer's inputs (exp / normalize / sigmoid of the final values) next to the raw ones and
     # the activation backward runs inside the deformation backward's first pass -- no activation launch in either direction
-    fuse = (cov3D_precomp is None and _standard_activations(pc) and getattr(pc._deformation, "supports_activated", False)
+    fuse = (FUSE_ACTIVATIONS and cov3D_precomp is None and _standard_activations(pc) and getattr(pc._deformation, "supports_activated", False)
             and (disable_filter3D or getattr(pc, "fused_filter3D", False)))
     kw = dict(activated=(None if disable_filter3D else pc.filter_3D,)) if fuse else {}
     (means3D_final, scales_final, rotations_final, opacity_final, shs_final, extras) = pc._deformation(

@@ -133,13 +133,16 @@ typedef struct ed3dgs_state_view {
     const float *accum_coord;     /* [3][H][W] */
     const float *accum_depth;     /* [H][W] */
     const float *normal_length;   /* [H][W] */
+    const uint32_t *depth_order;  /* [P] binning level 1: Gaussian ids by depth bits, ties by id, culled ones last */
 } ed3dgs_state_view;
 int ed3dgs_state_view_get(int P, int width, int height, int R, const char *geometry_buffer,
                           const char *binning_buffer, const char *image_buffer, ed3dgs_state_view *out);
 
 /* The scalars train.py logs per rendered frame (train.py:232-244, 300-330: image loss, PSNR), in one launch: out3 = {sum(image *
  * weight), -10 log10(mean((image - mid)^2)), 1} over n floats -- the vector the multi-GPU path all-reduces.
- * `acc` = 3 floats of device scratch, zero before the first call; every call leaves them zero.  16-byte aligned inputs. */
+ * `acc` = ED3DGS_STATS_ACC_FLOATS floats of device scratch (16 accumulator lines + the ticket word), zero before the first call;
+ * every call leaves them zero.  16-byte aligned inputs. */
+#define ED3DGS_STATS_ACC_FLOATS 272
 int ed3dgs_image_stats(const float *image, const float *weight, size_t n, float mid, float *acc, float *out3, void *stream);
 
 /* Measurement aid (bench.py): the bf16 MFMA rate the chip SUSTAINS -- v_mfma_f32_32x32x16_bf16 back to back on random operands in

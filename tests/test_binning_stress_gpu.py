@@ -82,11 +82,39 @@ def test_lists_bit_exact(case):
 
 @pytest.mark.parametrize("case", ["giants-1080p", "pile", "identical-depths", "deep-range-9k", "one-row", "1025-rows"])
 def test_handwritten_depth_sort_agrees(case, libopt):
-    """ED3DGS_SORT_HANDWRITTEN=1: the three-pass radix sort of csrc/binning.hip in place of the library's sort for binning level 1
-    (opt-in: bit-identical, fewer launches, but slower at 200k keys -- DESIGN.md)."""
+    """ED3DGS_SORT_HANDWRITTEN=1: the bucket + rank sort of csrc/binning.hip (round 4: 3 launches) in place of the library's stable
+    sort for binning level 1 -- opt-in: bit-identical, a little shorter on the GPU, no faster for the step."""
     _need_gpu()
     libopt("SORT_HANDWRITTEN", 1)
     _lists_equal(*CASES[case]())
+
+
+def test_depth_order_is_the_stable_sort_of_the_keys():
+    """The whole permutation, not only what the tile lists show of it: order[] of the hand-written sort against torch's stable
+    sort of the depth keys, culled Gaussians (key 0xFFFFFFFF) last and in id order, on a frame with ties, culled rows, a deep
+    depth range and more than one bucket block; and against the library's sort."""
+    _need_gpu()
+    from ed3dgs_amd import _lib
+    inp = dict(util.scene_inputs(30000, 800, 608, scene_seed=41, cam_seed=42))
+    m = inp["means3D"].clone()
+    m[::7] = m[3]                                         # thousands of exact ties
+    m[1::5] *= torch.logspace(-2.0, 1.2, m[1::5].shape[0])[:, None]   # depths over many binades, some behind the camera
+    inp["means3D"] = m
+    orders = {}
+    for lib in (0, 1):
+        old = _lib.set_option("SORT_HANDWRITTEN", 1 - lib)
+        try:
+            out, sv = util.hip_forward_raw(inp, "FFF")
+            orders[lib] = sv["depth_order"].astype(np.int64)
+        finally:
+            _lib.set_option("SORT_HANDWRITTEN", old)
+        keys = np.where(out[9].cpu().numpy() > 0, sv["depths"].view(np.uint32).astype(np.int64), 0xFFFFFFFF)
+    vis = out[9].cpu().numpy() > 0
+    assert 0.05 < vis.mean() < 0.99
+    # K1's key of a culled Gaussian is 0xFFFFFFFF whatever its depth; a visible one's is its depth bits
+    want = torch.sort(torch.from_numpy(keys), stable=True).indices.numpy()
+    assert np.array_equal(orders[0], want)
+    assert np.array_equal(orders[1], want)
 
 
 @pytest.mark.parametrize("switch,path", [("BIN_ONE_LEVEL", 1), ("BIN_RADIX", 0)])

@@ -80,7 +80,7 @@ def test_image_stats_matches_torch():
     from ed3dgs_amd import _lib
     L = _lib.lib()
     g = torch.Generator(device="cuda").manual_seed(3)
-    acc = torch.zeros(4, device="cuda")
+    acc = torch.zeros(272, device="cuda")   # ED3DGS_STATS_ACC_FLOATS
     for n in (3 * 1080 * 1920, 1027, 4, 3):
         img = torch.rand(n, generator=g, device="cuda")
         w = torch.randn(n, generator=g, device="cuda") / n
