@@ -524,7 +524,7 @@ def main():
     # HBM traffic per launch: NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes); read from the
     # newest committed summary of such passes over this same command, and labelled as such (`traffic_source`)
     pmc, traffic_source = {}, None
-    for prof_name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for prof_name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         prof = os.path.join(ROOT, "profiles", prof_name)
         if not os.path.exists(prof):
             continue
@@ -615,16 +615,38 @@ def main():
     roof_k6 = {"bound": "hbm", "kernel": "render_forward_kernel<false,true> (K6)", "achieved": bytes_k6 / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else 0.0,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (bytes_k6 / (k6_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k6_ms > 0 else 0.0,
                "traffic": pmc.get("render_forward_kernel<false,true>"), "traffic_source": traffic_source,
+               "traffic_over_algorithmic": (pmc.get("render_forward_kernel<false,true>") / bytes_k6) if (pmc.get("render_forward_kernel<false,true>") and bytes_k6 > 0) else None,
                "algorithmic_bytes_per_launch": bytes_k6, "avg_launch_ms": k6_ms, "valu_roof": valu_roof_k6}
     roof_k7 = {"bound": "hbm", "kernel": "render_backward_kernel<false,true> (K7)", "achieved": ach,
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                "traffic": pmc.get("render_backward_kernel<false,true>"), "traffic_source": traffic_source,
+               "traffic_over_algorithmic": (pmc.get("render_backward_kernel<false,true>") / bytes_k7) if (pmc.get("render_backward_kernel<false,true>") and bytes_k7 > 0) else None,
                "algorithmic_bytes_per_launch": bytes_k7, "avg_launch_ms": k7_ms, "launches": slot_n[1] or tab_n[1],
                "time_source": "timed region" if slot_n[1] else "instrumented pass of the same steps (hipEvent pairs on the launch stream)",
                "pairs_per_s_upper": mean(npairs_ub) / (k7_ms * 1e-3) if k7_ms > 0 else 0.0,
                "valu_roof": valu_roof,
                "note": "K7 is fp32-VALU-bound (arithmetic intensity >> machine balance, SURVEY 8d); the HBM fraction is "
                        "reported as defined there, next to the pair rate"}
+    # HBM bytes per launch from the committed PMC passes beside each kernel's ALGORITHMIC bytes (SURVEY 8d's per-unit figures x the
+    # units this run's launches processed): traffic well above the algorithmic bytes is wasted re-reading, the first thing to fix
+    alg_bytes = {"render_forward_kernel<false,true> (K6)": bytes_k6, "render_backward_kernel<false,true> (K7)": bytes_k7,
+                 "preprocess_backward_kernel (K8+K9)": 8.0 * wl["P"] + 755.0 * (mean(active_rows) if active_rows else wl["P"])}
+    if dm:
+        kept_b = 2 * 6 * 128 * 4.0   # relu(hid), relu(z_k): 6 x 128 floats per Gaussian and stage (the training forward writes them)
+        alg_bytes[K[2][0]] = (364.0 + 236.0) * wl["P"]                        # 364 B in + 236 B out per Gaussian
+        alg_bytes[K[3][0]] = (192.0 + 236.0 + 128.0 + 2 * 512.0) * rows_bwd    # sign masks + upstream rows + embedding + g_hid of both stages, active rows
+        alg_bytes[K[7][0]] = (4 / 5.0) * kept_b * rows_bwd + 1024.0 * rows_bwd # the four narrow heads' kept tiles + a of both stages
+        alg_bytes[K[6][0]] = (1 / 5.0) * kept_b * rows_bwd + 1024.0 * rows_bwd
+        alg_bytes[K[5][0]] = (2 * 512.0 + 128.0) * rows_bwd
+    for nm_, kd in kernels.items():
+        if not isinstance(kd, dict):
+            continue
+        tr = pmc.get(nm_.split(" ")[0])
+        kd["traffic"] = tr
+        if nm_ in alg_bytes:
+            kd["algorithmic_bytes_per_launch"] = alg_bytes[nm_]
+            kd["traffic_over_algorithmic"] = (tr / alg_bytes[nm_]) if (tr and alg_bytes[nm_] > 0) else None
+    kernels["_traffic_source"] = traffic_source
     if dom >= 2 and dm:
         nm, mac, pr = K[dom]
         rows_dom = wl["P"] if dom == 2 else rows_bwd
@@ -632,6 +654,9 @@ def main():
         peak = MFMA_BF16_PEAK_TFLOPS if pr > 1 else MFMA_F32_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": nm, "achieved": eq * pr, "peak": peak, "unit": "TFLOP/s", "frac": eq * pr / peak,
                 "traffic": pmc.get(nm.split(" ")[0]), "traffic_source": traffic_source,
+                "traffic_over_algorithmic": kernels.get(nm, {}).get("traffic_over_algorithmic"),
+                "traffic_note": "the training forward also WRITES the kept activations (6 x 128 floats per Gaussian and stage: 1.23 GB at "
+                                "200k) for the backward's weight-gradient kernels; they are not part of the 600 B / Gaussian of algorithmic I/O",
                 "algorithmic_flops_per_launch": 2.0 * mac * rows_dom, "executed_matrix_flops_per_launch": 2.0 * mac * rows_dom * pr,
                 "fp32_equivalent_TFLOPs": eq, "avg_launch_ms": avg_ms[dom], "launches": slot_n[dom],
                 "frac_of_measured_sustained_rate": (eq * pr / mfma_ceiling["bf16_32x32x16_TFLOPs"]) if (mfma_ceiling and pr > 1) else None,

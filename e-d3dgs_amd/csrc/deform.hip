@@ -43,6 +43,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef ED3_NP3_SMAX
 #define ED3_NP3_SMAX 3
 #endif
+// ED3_OPAQUE(x): the compiler may not look through x from here on.  Used on the Gaussian / thread index right where a per-lane
+// ADDRESS is formed from it late in a kernel: formed once in front of the tile loops, such addresses (64-bit pairs) stayed live across
+// every MFMA tile of the forward and were spilled -- 52 B of scratch per lane in round 3 (80 B with the activated outputs), 0 scratch
+// instructions now.  -DED3_FWD_OPAQUE_ADDR=0 builds the round-3 form (tools/ab_build.sh) for the before / after timing.
+#ifndef ED3_FWD_OPAQUE_ADDR
+#define ED3_FWD_OPAQUE_ADDR 1
+#endif
+#if ED3_FWD_OPAQUE_ADDR
+#define ED3_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define ED3_OPAQUE(x) ((void)0)
+#endif
 
 __device__ __forceinline__ int fslot(int kk, int h) { return (kk & 3) + 8 * (kk >> 2) + 4 * h; }
 
@@ -897,6 +909,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             float *const *dst = (s == 0) ? d.sub : d.out;
+            // (the output addresses are formed HERE from an opaque copy of g: computed once per block iteration in front of the tile
+            // loops they stayed live -- as 64-bit pairs -- across every MFMA tile and went to scratch)
+            int ge = g;
+            ED3_OPAQUE(ge);
             if (gvalid && dst[0]) {   // a tail unit owns one head's tensors (a disabled head's pass-through goes with head 0)
                 const bool w0 = konly <= 0, w1 = konly < 0 || konly == 1 || (konly == 0 && !d.enabled[1]);
                 const bool w2 = konly < 0 || konly == 2 || (konly == 0 && !d.enabled[2]);
@@ -905,28 +921,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (h == 0) {
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
-                        if (w0) dst[0][(size_t)g * 3 + i] = cx[i];
-                        if (w1) dst[1][(size_t)g * 3 + i] = cs[i];
+                        if (w0) dst[0][(size_t)ge * 3 + i] = cx[i];
+                        if (w1) dst[1][(size_t)ge * 3 + i] = cs[i];
                     }
-                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
-                    if (w3) dst[3][g] = co;
+                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)ge * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    if (w3) dst[3][ge] = co;
                     // the rasterizer's inputs straight from the strip's registers (gaussian_renderer/__init__.py:77-81: normalize,
                     // exp, sigmoid -- the 3D-filter variant couples opacity to the scales and takes the stand-alone launch): the
                     // owner of a head's tensor writes its activated twin as well
                     if (s == 1 && d.act[0]) {
                         if (w1) {
 #pragma unroll
-                            for (int i = 0; i < 3; i++) d.act[0][(size_t)g * 3 + i] = expf(cs[i]);
+                            for (int i = 0; i < 3; i++) d.act[0][(size_t)ge * 3 + i] = expf(cs[i]);
                         }
-                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)g * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
-                        if (w3) d.act[2][g] = act_sigmoid(co);
+                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)ge * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
+                        if (w3) d.act[2][ge] = act_sigmoid(co);
                     }
                 }
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) {
                     const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
                     if (w4 && feat < shw)
-                        *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
+                        *reinterpret_cast<float4 *>(dst[4] + (size_t)ge * shw + feat) =
                             make_float4(csh[4 * cc], csh[4 * cc + 1], csh[4 * cc + 2], csh[4 * cc + 3]);
                 }
             }
@@ -1108,7 +1124,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int s = 0; s < 2; s++) {
             if (d.use_stage[s]) {
                 const float *fr = d.frag[s];
-                for (int e = tid; e < NBIAS; e += 256) bias_s[e] = fr[d.fl.B2 + e];   // B2 | B3 | HB, as frag_layout orders them
+                int tl = tid;   // (opaque: the per-lane source address is formed here, not hoisted over the whole kernel into scratch)
+                ED3_OPAQUE(tl);
+                for (int e = tl; e < NBIAS; e += 256) bias_s[e] = fr[d.fl.B2 + e];   // B2 | B3 | HB, as frag_layout orders them
                 __syncthreads();   // (the previous stage's last tile ended with a barrier: nobody still reads the old values)
                 const float *bias_hb = bias_s + (d.fl.HB - d.fl.B2), *bias_b2 = bias_s, *bias_b3 = bias_s + (d.fl.B3 - d.fl.B2);
                 unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
@@ -1116,7 +1134,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 {
                     // the embedding tile is re-read per stage (L2) rather than held split across the head loops
                     float eb[1][16];
-                    load_emb_slots(d.emb, d.E, g, 0, h, eb[0]);
+                    int gl = g;   // (address formed here, per stage: see the note at the output stores)
+                    ED3_OPAQUE(gl);
+                    load_emb_slots(d.emb, d.E, gl, 0, h, eb[0]);
                     XSplitN<NP> ebs;
                     split_tile_n<NP>(eb[0], ebs);
                     const float *wb = PIPE_CUR();
@@ -1251,6 +1271,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int i = 0; i < 8; i++) d.timing[wave * 8 + i] = i < 7 ? tph[i] : ntile;
             }
             float *const *dst = (s == 0) ? d.sub : d.out;
+            // (the output addresses are formed HERE from an opaque copy of g: computed once per block iteration in front of the tile
+            // loops they stayed live -- as 64-bit pairs -- across every MFMA tile and went to scratch)
+            int ge = g;
+            ED3_OPAQUE(ge);
             if (gvalid && dst[0]) {   // a tail unit owns one head's tensors (a disabled head's pass-through goes with head 0)
                 const bool w0 = konly <= 0, w1 = konly < 0 || konly == 1 || (konly == 0 && !d.enabled[1]);
                 const bool w2 = konly < 0 || konly == 2 || (konly == 0 && !d.enabled[2]);
@@ -1259,28 +1283,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (h == 0) {
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
-                        if (w0) dst[0][(size_t)g * 3 + i] = cx[i];
-                        if (w1) dst[1][(size_t)g * 3 + i] = cs[i];
+                        if (w0) dst[0][(size_t)ge * 3 + i] = cx[i];
+                        if (w1) dst[1][(size_t)ge * 3 + i] = cs[i];
                     }
-                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)g * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
-                    if (w3) dst[3][g] = co;
+                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)ge * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    if (w3) dst[3][ge] = co;
                     // the rasterizer's inputs straight from the strip's registers (gaussian_renderer/__init__.py:77-81: normalize,
                     // exp, sigmoid -- the 3D-filter variant couples opacity to the scales and takes the stand-alone launch): the
                     // owner of a head's tensor writes its activated twin as well
                     if (s == 1 && d.act[0]) {
                         if (w1) {
 #pragma unroll
-                            for (int i = 0; i < 3; i++) d.act[0][(size_t)g * 3 + i] = expf(cs[i]);
+                            for (int i = 0; i < 3; i++) d.act[0][(size_t)ge * 3 + i] = expf(cs[i]);
                         }
-                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)g * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
-                        if (w3) d.act[2][g] = act_sigmoid(co);
+                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)ge * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
+                        if (w3) d.act[2][ge] = act_sigmoid(co);
                     }
                 }
 #pragma unroll
                 for (int cc = 0; cc < 6; cc++) {
                     const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
                     if (w4 && feat < shw)
-                        *reinterpret_cast<float4 *>(dst[4] + (size_t)g * shw + feat) =
+                        *reinterpret_cast<float4 *>(dst[4] + (size_t)ge * shw + feat) =
                             make_float4(csh[4 * cc], csh[4 * cc + 1], csh[4 * cc + 2], csh[4 * cc + 3]);
                 }
             }

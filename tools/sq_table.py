@@ -19,8 +19,8 @@ cols = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WA
         "SQ_LDS_BANK_CONFLICT"]
 lines = [f"# {tag} SQ counter pass (rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT "
          "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES)", "",
-         "Command: `rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --no-cpu-baseline --no-other-modes --steps 4 --warmup 1` "
-         "(C3, default multiply mode). Means per dispatch.",
+         "Command: `rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --no-cpu-baseline --no-other-modes [--train-only from round 4 on: "
+         "every launch a training-step launch] --steps 4 --warmup 1` (C3, default multiply mode). Means per dispatch.",
          f"`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (average duration x 2.4 GHz x 1024 SIMDs), duration from the counter-free "
          f"`{tag}_bench_c3_kernel_stats.md` (all launches of the kernel in that run: for the deformation forward that mixes the keeping "
          "launches of training with the non-keeping ones of the fps pass);",
