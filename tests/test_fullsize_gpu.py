@@ -36,8 +36,7 @@ def test_c2_forward_and_backward_parity_100k_1080p():
     # pixels with a blend decision within rounding of its threshold get no upstream gradient on either side (a pair
     # taken by one implementation and skipped by the other is a 1/255-sized term; see test_backward_ragged_sizes)
     goodf = torch.from_numpy(good.astype(np.float32))
-    print("masked (threshold-marginal) pixel fraction: %.2e" % float(1 - goodf.mean()))
-    assert float(1 - goodf.mean()) <= 1e-3
+    # (the excluded fraction was printed and held to MAX_MASKED_FRAC = 3e-4 by _check_images above)
     for k in grads:
         grads[k] = grads[k] * goodf
     fw_hip = dict(fw)
