@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -217,10 +218,16 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
         if (rb.seq == 0u) rb.seq = 1u;
         mail.counter = pd.counter; mail.host_word = pd.word; mail.seq = rb.seq;
     }
+    // diagnostic (ED3DGS_HOST_TIMING=1): where the HOST is between K1's launch and the last launch of the binning -- stderr, every 100 frames
+    const bool ht = opt(OPT_HOST_TIMING) != 0;
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double th[6] = {0, 0, 0, 0, 0, 0};
+    if (ht) th[0] = now_us();
     launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, tongue_class, shs, cov3D_precomp,
                       colors_precomp, viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy, focal_x,
                       focal_y, kernel_size, radii, geom, s, invraycov, condition, mail);
     if (!ok("preprocess")) return ED3DGS_ERR_HIP;
+    if (ht) th[1] = now_us();
     if (by_copy) {
         if (rb.cap < nblk) {
             if (rb.host) (void)hipHostFree(rb.host);
@@ -234,10 +241,8 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
         if (!check_hip(hipEventRecord(rb.ev, s), "read-back event record")) return ED3DGS_ERR_HIP;
     }
     // binning level 1: the Gaussians by depth.  The library's stable sort (rocPRIM merge sort below a million keys: 9 launches, 61 us
-    // at 200k) is the default; ED3DGS_SORT_HANDWRITTEN=1 runs the bucket + rank sort of binning.hip instead (3 launches, 55 us,
-    // bit-identical order).  Round 4 measured why neither a faster sort nor fewer launches moves the step: the host needs the
-    // ~60 us this sort takes to receive K1's count, allocate the binning state and enqueue level 2 -- with the shorter sort the
-    // stream runs dry in front of bin2_countA instead.
+    // at 200k) is the default; ED3DGS_SORT_HANDWRITTEN=1 runs the bucket + rank sort of binning.hip instead (3 launches, bit-identical
+    // order; 55-73 us depending on the view: its scattered global atomics make it the slower one on average -- profiles/r04_depth_sort_ab.md)
     if (!depth_sort_handwritten(P)) {
         if (!run_sort(geom.sort_space, geom.sort_size, geom.depth_keys, geom.depth_keys_sorted, geom.ids, geom.order, P, 32, s)) return ED3DGS_ERR_HIP;
     } else if (!launch_depth_sort(geom, P, s)) return ED3DGS_ERR_HIP;
@@ -248,6 +253,7 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
         if (!check_hip(hipMemsetAsync(img.ranges, 0, T * 2 * sizeof(uint32_t), s), "memset ranges")) return ED3DGS_ERR_HIP;
     }
     if (!ok("depth order")) return ED3DGS_ERR_HIP;
+    if (ht) th[2] = now_us();
     uint64_t num_rendered_u = 0;
     if (by_copy) {
         if (!check_hip(hipEventSynchronize(rb.ev), "sync num_rendered")) return ED3DGS_ERR_HIP;
@@ -274,6 +280,7 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     }
     if (num_rendered_u > 0x7fffffffu) { set_error("num_rendered overflows int"); return ED3DGS_ERR_INVALID; }
     const int R = (int)num_rendered_u;
+    if (ht) th[3] = now_us();
 
     // (the transpose's counters ride at the END of the binning buffer: the backward carves the same layout from R alone)
     const size_t tr_bytes = transpose ? bin_transpose_bytes(P, width, height, R) : 0;
@@ -281,11 +288,24 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
     if (!bin_chunk) { set_error("binning allocation failed"); return ED3DGS_ERR_ALLOC; }
     char *bin_end = bin_chunk;
     bin = BinningState::from_chunk(bin_end, R);
+    if (ht) th[4] = now_us();
 
     if (tr_bytes) {
         launch_bin_transpose(P, width, height, R, geom, radii, bin_end, img.ranges, img.tile_order, bin.tile_keys, bin.point_list,
                              bin.point_list_unsorted, bin.tile_keys_unsorted, s);
         if (!ok("binTranspose")) return ED3DGS_ERR_HIP;
+        if (ht) {
+            th[5] = now_us();
+            static thread_local double acc[5] = {0, 0, 0, 0, 0};
+            static thread_local int nacc = 0;
+            for (int i = 0; i < 5; i++) acc[i] += th[i + 1] - th[i];
+            if (++nacc == 100) {
+                fprintf(stderr, "[ed3dgs] host us per frame (mean of 100): K1 launch %.1f | level-1 sort launches %.1f | wait for the count %.1f | "
+                                "binning allocation callback %.1f | level-2 launches %.1f\n", acc[0] / 100, acc[1] / 100, acc[2] / 100, acc[3] / 100, acc[4] / 100);
+                nacc = 0;
+                for (int i = 0; i < 5; i++) acc[i] = 0;
+            }
+        }
         return R;
     }
     launch_duplicate_with_keys(P, geom, radii, width, height, bin.tile_keys_unsorted, bin.point_list_unsorted, s);

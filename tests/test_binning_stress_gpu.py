@@ -83,7 +83,7 @@ def test_lists_bit_exact(case):
 @pytest.mark.parametrize("case", ["giants-1080p", "pile", "identical-depths", "deep-range-9k", "one-row", "1025-rows"])
 def test_handwritten_depth_sort_agrees(case, libopt):
     """ED3DGS_SORT_HANDWRITTEN=1: the bucket + rank sort of csrc/binning.hip (round 4: 3 launches) in place of the library's stable
-    sort for binning level 1 -- opt-in: bit-identical, a little shorter on the GPU, no faster for the step."""
+    sort for binning level 1 -- opt-in: bit-identical, fewer launches, slower on average."""
     _need_gpu()
     libopt("SORT_HANDWRITTEN", 1)
     _lists_equal(*CASES[case]())
