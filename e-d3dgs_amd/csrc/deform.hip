@@ -1066,6 +1066,94 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
     return acc;
 }
 
+// The 2 NT k-steps of one head-hidden tile (z tile = W2 tile row x the strip's a): per k-step three weight pieces from LDS and the
+// eight piece products.  ED3_FWD_ROT (round 4): the pieces ROTATE through their three registers -- the products are ordered so that
+// piece 2 is dead after the third MFMA of a step, piece 1 after the sixth, piece 0 after the eighth (still smallest magnitude group
+// first: {w2 x1, w1 x2} {w2 x0, w1 x1, w0 x2} {w1 x0, w0 x1} {w0 x0}), and each register's NEXT-step load is issued the moment it dies,
+// 5 / 2 / 0 MFMAs ahead of the end of the step and at least 4 MFMAs (128 cycles) ahead of its first use: the LDS latency of a step's
+// weights runs under the wave's own MFMAs with no extra registers.  The plain form (gemm_tile_bn) reads a step's three pieces
+// together and waits lgkmcnt(0) in front of its first MFMA: ~150 cycles per k-step in which only the SIMD's other wave can keep
+// the matrix pipe busy.  -DED3_FWD_ROT=0 builds the plain form (A/B).
+#ifndef ED3_FWD_ROT
+#define ED3_FWD_ROT 2
+#endif
+#ifndef ED3_DGRAD_ROT
+#define ED3_DGRAD_ROT 1   // the same rotation (counted waits) in the data gradient's g_a tiles; 0: the plain form
+#endif
+// ED3_FWD_ROT == 2: the same rotation with the LDS reads and their COUNTED waits written out (ds_read_b128 / s_waitcnt lgkmcnt(n) in
+// inline assembly).  Needed because the compiler gives up counting lgkmcnt once an LDS-DMA (global_load_lds) has been issued in the
+// kernel -- every later wait for an LDS read becomes lgkmcnt(0) (reproduced in a 40-line kernel: counted waits before the first
+// LDS-DMA, lgkmcnt(0) after it) -- which in the rotated form would wait for the load issued a moment ago.  The waits are safe by
+// construction: LDS operations of a wave complete in order, and each wait allows exactly the loads issued AFTER the awaited one; an
+// LDS operation the compiler might add in between only makes a wait stricter.  Each wait carries its register as an in/out operand so
+// that no MFMA can be scheduled above it.
+typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
+#define ED3_LDS_READ128(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_))
+#define ED3_LGKM_WAIT(N_, REG_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(REG_))
+#define ED3_MF(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+#define ED3_MFU(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), B_, C_, 0, 0, 0)
+#define ED3_HEAD_TILE_MFMAS(ACC_)                                                                                                \
+    if constexpr (NP == 3 && ED3_FWD_ROT == 2 && ED3_NP3_SMAX == 3) {                                                             \
+        const uint32_t wa_ = (uint32_t)(uintptr_t)wb + (uint32_t)lane * 16u;   /* LDS byte address of this lane's fragment */     \
+        u32x4r w2_, w1_, w0_;                                                                                                    \
+        ED3_LDS_READ128(w2_, wa_, 2048); ED3_LDS_READ128(w1_, wa_, 1024); ED3_LDS_READ128(w0_, wa_, 0);                          \
+        _Pragma("unroll") for (int kt = 0; kt < NT; kt++) {                                                                      \
+            _Pragma("unroll") for (int st = 0; st < 2; st++) {                                                                   \
+                constexpr int dummy_ = 0; (void)dummy_;                                                                          \
+                const int s1_ = 2 * kt + st + 1;                                                                                 \
+                const bool more_ = s1_ < 2 * NT;                                                                                 \
+                const bf16x8 x0_ = as[kt].p[0][st], x1_ = as[kt].p[1][st], x2_ = as[kt].p[2][st];                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ED3_LGKM_WAIT(2, w2_); ACC_ = ED3_MFU(w2_, x1_, ACC_);                                                           \
+                ED3_LGKM_WAIT(1, w1_); ACC_ = ED3_MFU(w1_, x2_, ACC_); ACC_ = ED3_MFU(w2_, x0_, ACC_);                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) ED3_LDS_READ128(w2_, wa_, ED3_ROT_OFF(kt, st, 2));                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MFU(w1_, x1_, ACC_);                                                                                  \
+                if (more_) { ED3_LGKM_WAIT(1, w0_); } else { ED3_LGKM_WAIT(0, w0_); }                                            \
+                ACC_ = ED3_MFU(w0_, x2_, ACC_); ACC_ = ED3_MFU(w1_, x0_, ACC_);                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) ED3_LDS_READ128(w1_, wa_, ED3_ROT_OFF(kt, st, 1));                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MFU(w0_, x1_, ACC_); ACC_ = ED3_MFU(w0_, x0_, ACC_);                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) ED3_LDS_READ128(w0_, wa_, ED3_ROT_OFF(kt, st, 0));                                                    \
+            }                                                                                                                    \
+            GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                                               \
+        }                                                                                                                        \
+    } else if constexpr (NP == 3 && ED3_FWD_ROT == 1 && ED3_NP3_SMAX == 3) {                                                      \
+        const bf16x8 *wq_ = reinterpret_cast<const bf16x8 *>(wb) + lane;                                                         \
+        bf16x8 w2_ = wq_[2 * 64], w1_ = wq_[1 * 64], w0_ = wq_[0];                                                               \
+        _Pragma("unroll") for (int kt = 0; kt < NT; kt++) {                                                                      \
+            _Pragma("unroll") for (int st = 0; st < 2; st++) {                                                                   \
+                const int s1_ = 2 * kt + st + 1;                                                                                 \
+                const bool more_ = s1_ < 2 * NT;                                                                                 \
+                const bf16x8 x0_ = as[kt].p[0][st], x1_ = as[kt].p[1][st], x2_ = as[kt].p[2][st];                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MF(w2_, x1_, ACC_); ACC_ = ED3_MF(w1_, x2_, ACC_); ACC_ = ED3_MF(w2_, x0_, ACC_);                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) w2_ = wq_[(3 * s1_ + 2) * 64];                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MF(w1_, x1_, ACC_); ACC_ = ED3_MF(w0_, x2_, ACC_); ACC_ = ED3_MF(w1_, x0_, ACC_);                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) w1_ = wq_[(3 * s1_ + 1) * 64];                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MF(w0_, x1_, ACC_); ACC_ = ED3_MF(w0_, x0_, ACC_);                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) w0_ = wq_[(3 * s1_) * 64];                                                                            \
+            }                                                                                                                    \
+            GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                                               \
+        }                                                                                                                        \
+    } else {                                                                                                                     \
+        _Pragma("unroll") for (int kt = 0; kt < NT; kt++) {                                                                      \
+            ACC_ = gemm_tile_bn<NP>(wb + kt * TS, as[kt], ACC_, lane);                                                           \
+            GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                                               \
+        }                                                                                                                        \
+    }
+// byte offset of piece Q_ of the k-step AFTER (kt, st): an "n" (immediate) operand, so it has to be a constant expression of the
+// unrolled loop indices -- the switch below spells the 2 NT <= 8 cases out
+#define ED3_ROT_OFF(KT_, ST_, Q_) ((3 * (2 * (KT_) + (ST_) + 1) + (Q_)) * 1024)
+
 template <int NT, int NP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_forward_b3_kernel(DeformDev d)
 {
@@ -1176,11 +1264,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             load_bias4(bv, bias_b2 + k * d.W, nt, h);
                             f32x16 acc = zero_acc();
                             GPIPE_SPREAD_BEGIN()
-#pragma unroll
-                            for (int kt = 0; kt < NT; kt++) {
-                                acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
-                                GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
-                            }
+                            ED3_HEAD_TILE_MFMAS(acc)
                             FW_MARK(0);
                             // the 16 W3 values of this lane are fetched from LDS in one go, ahead of the epilogue's VALU
                             // work: read-wait-MFMA per k-slot (what the compiler emits for the plain loop) is a chain of
@@ -1230,11 +1314,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             load_bias4(bv, bias_b2 + k * d.W, nt, h);
                             f32x16 acc = zero_acc();
                             GPIPE_SPREAD_BEGIN()
-#pragma unroll
-                            for (int kt = 0; kt < NT; kt++) {
-                                acc = gemm_tile_bn<NP>(wb + kt * TS, as[kt], acc, lane);
-                                GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
-                            }
+                            ED3_HEAD_TILE_MFMAS(acc)
                             float z[1][16];
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
@@ -1936,10 +2016,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     split_tile_n<NP>(z[0], zs);
                     // the next chunk's pieces go out between this tile's products (see GPIPE_SPREAD_BEGIN); no stores in a tile
                     GPIPE_SPREAD_BEGIN()
+                    if constexpr (NP == 3 && ED3_DGRAD_ROT && ED3_NP3_SMAX == 3) {
+                        // g_a tiles: the rotating weight pieces of the forward's head tiles (ED3_HEAD_TILE_MFMAS), here over the NT
+                        // row tiles of W2^T with ONE right-hand operand (this tile's g_z) and an accumulator per tile
+                        const uint32_t wa_ = (uint32_t)(uintptr_t)(wb + OTMAX * TS) + (uint32_t)lane * 16u;
+                        u32x4r w2_, w1_, w0_;
+                        ED3_LDS_READ128(w2_, wa_, 2048); ED3_LDS_READ128(w1_, wa_, 1024); ED3_LDS_READ128(w0_, wa_, 0);
 #pragma unroll
-                    for (int i2 = 0; i2 < NT; i2++) {
-                        GPIPE_PIECES(i2 * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
-                        ga[i2] = gemm_tile_bn<NP>(wb + (OTMAX + i2) * TS, zs, ga[i2], lane);
+                        for (int i2 = 0; i2 < NT; i2++) {
+                            GPIPE_PIECES(i2 * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
+#pragma unroll
+                            for (int st = 0; st < 2; st++) {
+                                const bool more_ = 2 * i2 + st + 1 < 2 * NT;
+                                const bf16x8 x0_ = zs.p[0][st], x1_ = zs.p[1][st], x2_ = zs.p[2][st];
+                                __builtin_amdgcn_sched_barrier(0);
+                                ED3_LGKM_WAIT(2, w2_); ga[i2] = ED3_MFU(w2_, x1_, ga[i2]);
+                                ED3_LGKM_WAIT(1, w1_); ga[i2] = ED3_MFU(w1_, x2_, ga[i2]); ga[i2] = ED3_MFU(w2_, x0_, ga[i2]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (more_) ED3_LDS_READ128(w2_, wa_, ED3_ROT_OFF(i2, st, 2));
+                                __builtin_amdgcn_sched_barrier(0);
+                                ga[i2] = ED3_MFU(w1_, x1_, ga[i2]);
+                                if (more_) { ED3_LGKM_WAIT(1, w0_); } else { ED3_LGKM_WAIT(0, w0_); }
+                                ga[i2] = ED3_MFU(w0_, x2_, ga[i2]); ga[i2] = ED3_MFU(w1_, x0_, ga[i2]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (more_) ED3_LDS_READ128(w1_, wa_, ED3_ROT_OFF(i2, st, 1));
+                                __builtin_amdgcn_sched_barrier(0);
+                                ga[i2] = ED3_MFU(w0_, x1_, ga[i2]); ga[i2] = ED3_MFU(w0_, x0_, ga[i2]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (more_) ED3_LDS_READ128(w0_, wa_, ED3_ROT_OFF(i2, st, 0));
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i2 = 0; i2 < NT; i2++) {
+                            GPIPE_PIECES(i2 * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
+                            ga[i2] = gemm_tile_bn<NP>(wb + (OTMAX + i2) * TS, zs, ga[i2], lane);
+                        }
                     }
                     GPIPE_SYNC_N(false, 0);
                 }
