@@ -1080,6 +1080,11 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
 #ifndef ED3_DGRAD_ROT
 #define ED3_DGRAD_ROT 1   // the same rotation (counted waits) in the data gradient's g_a tiles; 0: the plain form
 #endif
+#ifndef ED3_WGRAD_ROT
+#define ED3_WGRAD_ROT 1   // ... and in the head weight-gradient kernels' dW2 products (the B pieces: transposing LDS reads): 1 = the SH
+                          // head's launch only (measured: -1.2 %), 2 = the narrow heads' too (measured: +2.5 % -- the compiler's own
+                          // schedule hides the g_z split's VALU work under these MFMAs, the pinned one does not), 0 = neither
+#endif
 // ED3_FWD_ROT == 2: the same rotation with the LDS reads and their COUNTED waits written out (ds_read_b128 / s_waitcnt lgkmcnt(n) in
 // inline assembly).  Needed because the compiler gives up counting lgkmcnt once an LDS-DMA (global_load_lds) has been issued in the
 // kernel -- every later wait for an LDS read becomes lgkmcnt(0) (reproduced in a 40-line kernel: counted waits before the first
@@ -2866,6 +2871,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         WG_MARK(4);
         // dW2 row block: A = g_z (registers 8 s .. 8 s + 7 are k-step s: Gaussians 16 s + 8 (j >> 2) + 4 h + (j & 3)),
         // B = the a pieces of those Gaussians: quads 4 s + h and 4 s + 2 + h of the image
+        if constexpr (ED3_WGRAD_ROT == 2 || (ED3_WGRAD_ROT == 1 && WIDE)) {
+        // The eight (k-step, n-tile) steps of the slab with the B pieces ROTATING through their registers (see ED3_HEAD_TILE_MFMAS: the
+        // products ordered so that piece 2 dies after a step's 3rd MFMA, piece 1 after the 6th; each piece's next-step transposing
+        // reads -- two ds_read_b64_tr_b16 -- issued the moment it dies; counted lgkmcnt waits in inline assembly, because the compiler
+        // waits lgkmcnt(0) for every LDS read once an LDS-DMA is in flight, and this kernel always has one in flight)
+        if (!(a.ablate & 2)) {
+            const uint32_t ab_ = (uint32_t)(uintptr_t)aimg;
+            uint32_t au_[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) au_[u] = ab_ + (uint32_t)trb[u];
+            i16x4 b2l, b2h, b1l, b1h, b0l, b0h;
+#define ED3_TRR(LO_, HI_, U_, ST_, Q_)                                                                                                       \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(LO_), "=&v"(HI_)                      \
+                 : "v"(au_[U_]), "n"((3 * (U_) + (Q_)) * 2048 + (4 * (ST_)) * 256), "n"((3 * (U_) + (Q_)) * 2048 + (4 * (ST_) + 2) * 256))
+#define ED3_TRW(N_, LO_, HI_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(LO_), "+v"(HI_))
+#define ED3_B8(LO_, HI_) __builtin_bit_cast(bf16x8, (i16x8){LO_[0], LO_[1], LO_[2], LO_[3], HI_[0], HI_[1], HI_[2], HI_[3]})
+            ED3_TRR(b2l, b2h, 0, 0, 2); ED3_TRR(b1l, b1h, 0, 0, 1); ED3_TRR(b0l, b0h, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const bf16x8 a0 = gzs.p[0][st], a1 = gzs.p[1][st], a2 = gzs.p[2][st];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool more = 4 * st + u + 1 < 8;
+                    const int un = (u + 1) & 3, sn = st + ((u + 1) >> 2);   // the next step
+                    __builtin_amdgcn_sched_barrier(0);
+                    ED3_TRW(4, b2l, b2h); acc[u] = ED3_MF(a1, ED3_B8(b2l, b2h), acc[u]);
+                    ED3_TRW(2, b1l, b1h); acc[u] = ED3_MF(a2, ED3_B8(b1l, b1h), acc[u]); acc[u] = ED3_MF(a0, ED3_B8(b2l, b2h), acc[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) ED3_TRR(b2l, b2h, un, sn, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[u] = ED3_MF(a1, ED3_B8(b1l, b1h), acc[u]);
+                    if (more) { ED3_TRW(2, b0l, b0h); } else { ED3_TRW(0, b0l, b0h); }
+                    acc[u] = ED3_MF(a2, ED3_B8(b0l, b0h), acc[u]); acc[u] = ED3_MF(a0, ED3_B8(b1l, b1h), acc[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) ED3_TRR(b1l, b1h, un, sn, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[u] = ED3_MF(a1, ED3_B8(b0l, b0h), acc[u]); acc[u] = ED3_MF(a0, ED3_B8(b0l, b0h), acc[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) ED3_TRR(b0l, b0h, un, sn, 0);
+                }
+            }
+#undef ED3_TRR
+#undef ED3_TRW
+#undef ED3_B8
+        }
+        } else {
         if (!(a.ablate & 2))
 #pragma unroll
         for (int st = 0; st < 2; st++) {
@@ -2879,6 +2930,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int q = 0; q < 3; q++) bp[q] = tr_read2(aimg + trb[u], (3 * u + q) * 2048 + (4 * st) * 256, (3 * u + q) * 2048 + (4 * st + 2) * 256);
                 acc[u] = mfma_bn<3>(ga, bp, acc[u]);
             }
+        }
         }
         WG_MARK(5);
         if constexpr (WIDE) {
