@@ -100,14 +100,14 @@ def _render_impl(viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modi
     scales = pc._scaling
     rotations = pc._rotation
 
-    # viewpoint_camera.time is a Python number; the reference builds a (P,1) tensor of it (:45) of which the network reads
-    # element [0,0] (scene/deformation.py:58) -- a tensor is accepted just the same
     # north_star "the deformation MLP fused with the preprocess": when the model's activations are the reference's own, the MLP
     # kernel's epilogue writes the rasterizer's inputs (exp / normalize / sigmoid of the final values) next to the raw ones and
     # the activation backward runs inside the deformation backward's first pass -- no activation launch in either direction
     fuse = (FUSE_ACTIVATIONS and cov3D_precomp is None and _standard_activations(pc) and getattr(pc._deformation, "supports_activated", False)
             and (disable_filter3D or getattr(pc, "fused_filter3D", False)))
     kw = dict(activated=(None if disable_filter3D else pc.filter_3D,)) if fuse else {}
+    # (viewpoint_camera.time goes in as a Python number; the reference builds a (P,1) tensor of it (:45) of which the network
+    # reads element [0,0] (scene/deformation.py:58) -- a tensor is accepted just the same)
     (means3D_final, scales_final, rotations_final, opacity_final, shs_final, extras) = pc._deformation(
         means3D, scales, rotations, opacity, float(viewpoint_camera.time), cam_no, pc, None, shs, iter=iter,
         num_down_emb_c=num_down_emb_c, num_down_emb_f=num_down_emb_f, sh_coefs_rest=shs_rest, **kw)
