@@ -1080,6 +1080,9 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
 #ifndef ED3_DGRAD_ROT
 #define ED3_DGRAD_ROT 1   // the same rotation (counted waits) in the data gradient's g_a tiles; 0: the plain form
 #endif
+#ifndef ED3_DW1_BLOCKS
+#define ED3_DW1_BLOCKS 512   // blocks of the dW1 stream launch (all jobs together): 2 per CU at 40 KB of LDS each
+#endif
 #ifndef ED3_WGRAD_ROT
 #define ED3_WGRAD_ROT 1   // ... and in the head weight-gradient kernels' dW2 products (the B pieces: transposing LDS reads): 1 = the SH
                           // head's launch only (measured: -1.2 %), 2 = the narrow heads' too (measured: +2.5 % -- the compiler's own
@@ -4041,7 +4044,7 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
     const bool pw5 = prof_start(ED3DGS_PROF_DEFORM_WGRAD_TRUNK, s);
     if (dw1.njobs) {
         int nb = 0;
-        for (int q = 0; q < dw1.njobs; q++) { dw1.blk_begin[q] = nb; nb += std::max(1, std::min((cfg->P + 127) / 128, 512 / dw1.njobs)); }
+        for (int q = 0; q < dw1.njobs; q++) { dw1.blk_begin[q] = nb; nb += std::max(1, std::min((cfg->P + 127) / 128, ED3_DW1_BLOCKS / dw1.njobs)); }
         dw1.blk_begin[dw1.njobs] = nb;
         hipLaunchKernelGGL(deform_dw1_kernel, dim3(nb), dim3(256), (size_t)2 * (32 * 128 + 32 * 32) * sizeof(float), s, dw1);
     }
