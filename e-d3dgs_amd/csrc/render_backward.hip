@@ -445,7 +445,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             touched |= ((j0 >= 0 && (anyb & 0xFFFFull)) ? 1ull << j0 : 0ull) | ((j1 >= 0 && (anyb >> 16 & 0xFFFFull)) ? 1ull << j1 : 0ull) |
                        ((j2 >= 0 && (anyb >> 32 & 0xFFFFull)) ? 1ull << j2 : 0ull) | ((j3 >= 0 && (anyb >> 48)) ? 1ull << j3 : 0ull);
 #else
+#ifdef ED3_K7_ABLATE_ATOMICS   // timing experiment (results WRONG): the records are reduced and dropped
+            if (act && qany && z[0] == 123456.789f) {
+#else
             if (act && qany) {   // round 3: one 64-byte atomic per (tile, Gaussian, quadrant)
+#endif
                 const uint32_t id = s_id[j];
                 atomicAdd(grec + (size_t)id * GREC + li, z[0]);
                 if (COORD && li < 9) atomicAdd(grec_coord + (size_t)id * GREC + li, z[NV / 16 - 1]);
