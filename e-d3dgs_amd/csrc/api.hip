@@ -325,7 +325,7 @@ int bin_gaussians(ed3dgs_alloc_fn geometry_alloc, void *geometry_user, ed3dgs_al
 extern "C" {
 
 const char *ed3dgs_last_error(void) { return g_error.c_str(); }
-int ed3dgs_abi_version(void) { return 4; }
+int ed3dgs_abi_version(void) { return 5; }   // 5 (round 4): ed3dgs_deform_forward_activated / _backward_activated, ed3dgs_state_view.depth_order, ED3DGS_STATS_ACC_FLOATS
 
 int ed3dgs_set_option(const char *name, int value)
 {

@@ -38,7 +38,7 @@ extern "C" {
 typedef char *(*ed3dgs_alloc_fn)(void *user, size_t bytes);
 
 const char *ed3dgs_last_error(void);
-int ed3dgs_abi_version(void);
+int ed3dgs_abi_version(void);   /* 5 since round 4: + ed3dgs_deform_forward_activated / _backward_activated, ed3dgs_state_view.depth_order, ED3DGS_STATS_ACC_FLOATS */
 
 /* Process-wide switches (A/B modes and diagnostics; none changes a result beyond the stated tolerances).  Each is read from the
  * environment ONCE, when the library is loaded (ED3DGS_<NAME>=<int>), and afterwards only changed here; no entry point reads the

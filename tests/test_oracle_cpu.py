@@ -330,7 +330,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, missing
     assert set(_lib.EXPORTS) >= declared - {"ed3dgs_deform_cfg", "ed3dgs_state_view"}
-    assert L.ed3dgs_abi_version() == 4
+    assert L.ed3dgs_abi_version() == 5
     # process-wide switches: read from the environment once at load, then only ed3dgs_set_option (no GPU needed)
     assert _lib.get_option("ED3DGS_BIN_RADIX") == 0 and _lib.set_option("BIN_RADIX", 1) == 0 and _lib.get_option("BIN_RADIX") == 1
     assert L.ed3dgs_binning_path(1000, 1920, 1080) == 0
