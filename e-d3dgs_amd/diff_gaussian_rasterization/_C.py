@@ -42,17 +42,41 @@ def _num(x, typ):
     return typ(x.item() if torch.is_tensor(x) else x)
 
 
+# Capacity of the binning state per (device, P, H, W): the one per-frame allocation whose size depends on the DATA (the instance
+# count R).  Asked for at its exact size it is a different request every frame, and the caching allocator serves it by splitting
+# whatever large free block fits -- e.g. the 1.4-GB deformation workspace the previous step just returned -- after which that
+# workspace's next request fits nowhere and goes to hipMalloc: round 4 counted 36 device mallocs inside 40 timed steps and the
+# reserved memory growing from 3.6 to 10.7 GB, with steps of 7 ms among the 2.2-ms ones.  Asked for at a capacity that only ever
+# grows (1.25 x the largest count seen for the frame size), the request repeats exactly and the allocator hands back the same block.
+_BIN_CAPACITY = {}
+
+
 class _Grow:
     """Growable byte buffer handed to the library as an allocation callback (resizeFunctional,
-    DGR/rasterize_points.cu:27-33)."""
+    DGR/rasterize_points.cu:27-33).  `cap_key`: allocate at the remembered capacity of that key (the binning state, above)."""
 
-    def __init__(self, device):
+    def __init__(self, device, cap_key=None):
         self.device = device
+        self.cap_key = cap_key
         self.t = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _lib.ALLOC_FN(self._alloc)
+
+    @property
+    def cb(self):
+        # Made per call and never stored on the object: a stored callback (-> bound method -> self -> callback) is a reference
+        # cycle, and the state tensor in it then lives until the cyclic collector happens to run.  Round 4 measured what that
+        # costs: ~245 MB of state per step waiting for the collector, so every step went to hipMalloc for its three buffers
+        # (24 segment allocations in 8 steps), the reserved memory swung between 3.6 and 11.9 GB, and the timed region held
+        # windows of 7 ms/step.  The caller keeps the returned object alive for the duration of the library call.
+        return _lib.ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, nbytes):
-        self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        n = int(nbytes)
+        if self.cap_key is not None:
+            cap = _BIN_CAPACITY.get(self.cap_key, 0)
+            if n > cap:
+                cap = _BIN_CAPACITY[self.cap_key] = (int(n * 1.25) + (1 << 21) - 1) & ~((1 << 21) - 1)
+            n = cap
+        self.t = torch.empty(n, dtype=torch.uint8, device=self.device)
         return self.t.data_ptr()
 
 
@@ -98,7 +122,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, tongue_class, scal
     out_alpha, out_tongue = mk(1, True), mk(1, True)
     out_normal = mk(3, geo)
     radii = (torch.empty if run else torch.zeros)((P,), dtype=torch.int32, device=dev)
-    geom, binning, img = _Grow(dev), _Grow(dev), _Grow(dev)
+    geom, binning, img = _Grow(dev), _Grow(dev, (str(dev), P, H, W)), _Grow(dev)
     rendered = 0
     if run:
         M = sh.size(1) if sh.numel() else 0

@@ -440,3 +440,34 @@ def test_synthetic_camera_matrices():
     o = torch.tensor([0.0, 0, 0, 1]) @ V
     assert abs(float(o[0])) < 1e-5 and abs(float(o[1])) < 1e-5 and float(o[2]) > 3.5          # looks at the origin
     assert torch.allclose(cam.full_proj_transform, V @ cam.projection_matrix, atol=1e-6)
+
+
+def test_state_buffers_are_freed_by_reference_counting_alone():
+    """The allocation callbacks' holders must not sit in a reference cycle: a state tensor in one waits for the cyclic collector,
+    and a training step then goes to the device allocator for its buffers every time (round 4: 24 segment allocations in 8 steps,
+    reserved memory 3.6 -> 11.9 GB, 7-ms steps among 2.2-ms ones).  Also: the binning state is asked for at a capacity that only
+    grows per (device, P, H, W), so the one data-dependent request of a frame repeats exactly."""
+    import gc, weakref, ctypes
+    from diff_gaussian_rasterization import _C as rc
+    gc.collect(); gc.disable()
+    try:
+        g = rc._Grow(torch.device("cpu"))
+        cb = g.cb
+        ptr = cb(None, 1000)
+        assert ptr == g.t.data_ptr() and g.t.numel() == 1000
+        w = weakref.ref(g)
+        del g, cb
+        assert w() is None, "a _Grow object survived its last reference: it is part of a cycle"
+    finally:
+        gc.enable()
+    key = ("cpu-test", 1, 2, 3)
+    rc._BIN_CAPACITY.pop(key, None)
+    b = rc._Grow(torch.device("cpu"), key)
+    cb = b.cb
+    cb(None, 3_000_000); n1 = b.t.numel()
+    cb(None, 2_500_000); n2 = b.t.numel()
+    cb(None, 3_100_000); n3 = b.t.numel()
+    assert n1 >= 3_750_000 and n1 % (1 << 21) == 0 and n2 == n1 and n3 == n1      # 1.25 x, 2-MiB granules, never shrinks
+    cb(None, 5_000_000)
+    assert b.t.numel() >= 6_250_000
+    rc._BIN_CAPACITY.pop(key, None)
