@@ -216,6 +216,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mark-every", type=int, default=0, help="steps per step-time window of the timed region (default 4; a mark is a barrier packet on the stream)")
     ap.add_argument("--cpu-baseline-points", action="store_true", help="also time the CPU restatement at C1 (in full) and at the C2 point (SURVEY 8d); minutes of CPU work")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed extra passes in the MLP's other multiply modes (for profiles)")
     ap.add_argument("--sequential-items", action="store_true", help="rank r's k-th item is its k-th (camera 0, frames 0, 1, ... at N=1): round 2's "
@@ -383,6 +384,12 @@ def main():
     _C.KEEP_LAST = False
     _C.LAST.clear()
 
+    # The interpreter's cyclic collector: run now, then off until the timed region is over (a collection inside it showed as a
+    # 6-ms step of 2.2).  HERE and not in front of the timed region: a full collection is ~50 ms of idle GPU, after which the
+    # kernels run up to 15 % slower and recover over ~10 steps (kernel trace, round 4: the sum of a step's kernel durations
+    # 2.52 -> 2.17 ms over the twelve steps after the pause, no launch gaps -- the clock ramp).  The K-step pass below follows it.
+    import gc
+    gc.collect(); gc.disable()
     # ---- per-kernel table: an instrumented, UNTIMED pass (five event pairs per step cost stream time) ----
     L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(0x1FF))
     for k in range(a.steps):
@@ -420,8 +427,6 @@ def main():
     # stream, ~6 us of gap: K7 and the others are timed in the instrumented pass above) ----
     # The W warm-up steps once more, directly before the timed region: the bookkeeping passes above end in host-side reads
     # (an idle GPU, whose clock then ramps through the first timed steps: their window read 2.7-2.9 ms against 2.2).
-    import gc
-    gc.collect(); gc.disable()   # a cyclic-GC pause of the interpreter inside the timed region showed as a 6-ms step (of 2.2)
     for k in range(a.warmup):
         step(item_at(k))
     step.drain()
@@ -430,7 +435,7 @@ def main():
     L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(1 << dom))
     # step-time spread: a mark every MARK_EVERY steps on the launch stream (a mark is a barrier packet too: ~6 us of idle stream,
     # 0.3 % of a step if taken at every boundary)
-    MARK_EVERY = 4 if a.steps >= 8 else 1
+    MARK_EVERY = a.mark_every if a.mark_every > 0 else (4 if a.steps >= 8 else 1)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps // MARK_EVERY + 1)]
     n_malloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0) if torch.cuda.is_available() else 0
     t0 = time.perf_counter()
@@ -565,6 +570,10 @@ def main():
         6: ({"exact_split": "deform_head_wgrad_tr_kernel<true>", "bf16x3": "deform_head_wgrad_kernel<true,true,false> + deform_dw3_wide_kernel", "fp32_mfma": "deform_head_wgrad_kernel<true,false,true>"}[mode], mac_wide, {"exact_split": 8, "bf16x3": 3, "fp32_mfma": 1}[mode]),
         7: ({"exact_split": "deform_head_wgrad_tr_kernel<false>", "bf16x3": "deform_head_wgrad_kernel<false,true,true>", "fp32_mfma": "deform_head_wgrad_kernel<false,false,true>"}[mode], mac_narrow, npr),
     }
+    if mode == "exact_split" and tab_n[6] == 0 and tab_n[7] > 0:
+        # default since round 4: the SH head's and the narrow heads' weight gradients are ONE launch (timed under the narrow slot)
+        del K[6]
+        K[7] = ("deform_head_wgrad_tr_all_kernel", mac_wide + mac_narrow, npr)
     tfl = lambda mac, ms, rows=None: 2.0 * mac * (wl["P"] if rows is None else rows) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # the backward kernels walk only the rows with a non-zero upstream gradient (csrc/deform.hip, deform_active_rows_body):
     # their rates are priced on the rows they process, not on P
@@ -642,8 +651,11 @@ def main():
         kept_b = 2 * 6 * 128 * 4.0   # relu(hid), relu(z_k): 6 x 128 floats per Gaussian and stage (the training forward writes them)
         alg_bytes[K[2][0]] = (364.0 + 236.0) * wl["P"]                        # 364 B in + 236 B out per Gaussian
         alg_bytes[K[3][0]] = (192.0 + 236.0 + 128.0 + 2 * 512.0) * rows_bwd    # sign masks + upstream rows + embedding + g_hid of both stages, active rows
-        alg_bytes[K[7][0]] = (4 / 5.0) * kept_b * rows_bwd + 1024.0 * rows_bwd # the four narrow heads' kept tiles + a of both stages
-        alg_bytes[K[6][0]] = (1 / 5.0) * kept_b * rows_bwd + 1024.0 * rows_bwd
+        if 6 in K:
+            alg_bytes[K[7][0]] = (4 / 5.0) * kept_b * rows_bwd + 1024.0 * rows_bwd # the four narrow heads' kept tiles + a of both stages
+            alg_bytes[K[6][0]] = (1 / 5.0) * kept_b * rows_bwd + 1024.0 * rows_bwd
+        else:   # one launch: the blocks of either kind read a of both stages
+            alg_bytes[K[7][0]] = kept_b * rows_bwd + 2 * 1024.0 * rows_bwd
         alg_bytes[K[5][0]] = (2 * 512.0 + 128.0) * rows_bwd
     for nm_, kd in kernels.items():
         if not isinstance(kd, dict):

@@ -2663,8 +2663,11 @@ __device__ __forceinline__ int trimg_off(int g, int cc, int q)
     return (((nt * 3 + q) * 8 + (g >> 2)) << 8) + ((((g & 3) + nt) & 3) << 6) + ((cc & 7) << 3);
 }
 
+// The kernel's body: `bid` = the block's index among the launch's blocks of this kind (WIDE or not); the LDS objects are the
+// calling kernel's `__shared__` variables, handed over one by one (inlined: every access still names its object, see above).
 template <bool WIDE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_tr_kernel(HeadWgradArgs a)
+__device__ __forceinline__ void head_wgrad_tr_body(const HeadWgradArgs &a, const int bid, float *zbuf0, float *zbuf1, float *astage,
+                                                   char *aimg, float *gs, int *rid0, int *rid1)
 {
     constexpr int SLAB = 32 * HJ_W;                  // floats per fp32 slab
     constexpr int LDG = WIDE ? 49 : 5;               // g_y slab row stride (odd); the last column stays zero
@@ -2674,17 +2677,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // half the LDS-DMA pieces to issue (their issue is the largest non-MFMA item of a slab) and no staging round trip through
     // LDS.  The wide head has no 16 registers to spare and keeps the LDS-DMA staging buffer.
     constexpr bool AREG = !WIDE;
-    __shared__ float zbuf0[SLAB];
-    __shared__ float zbuf1[SLAB];
-    __shared__ float astage[AREG ? 4 : SLAB];
-    __shared__ __attribute__((aligned(256))) char aimg[24576];   // piece image of the a slab
-    __shared__ float gs[32 * LDG];
-    __shared__ int rid0[32];                         // Gaussian ids of a slab's 32 rows (two slabs: one being fetched, one in use);
-    __shared__ int rid1[32];                         // separate objects, like the z buffers
     int jb = 0;
-    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.blk_begin[jb + 1]) jb++;
+    while (jb + 1 < a.njobs && bid >= a.blk_begin[jb + 1]) jb++;
     const HeadJob &J = a.job[jb];
-    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = (int)blockIdx.x - a.blk_begin[jb];
+    const int nsplit = a.blk_begin[jb + 1] - a.blk_begin[jb], split = bid - a.blk_begin[jb];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = J.nk, P = a.rows ? __builtin_amdgcn_readfirstlane(*a.n_act) : a.P;   // rows to walk
@@ -2792,7 +2788,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int u = 0; u < 4; u++) trb[u] = (h << 8) + (((tr_row + u) & 3) << 6) + (tr_cc << 3);
 
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-    const bool timed = a.timing != nullptr && blockIdx.x == 0;
+    const bool timed = a.timing != nullptr && bid == 0;
 #define WG_MARK(i_) do { if (timed) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); tph[i_] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
     if (timed) tlast = clock64();
     int ids_next = fetch_ids(0);
@@ -2846,6 +2842,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
         // g_z tile of this wave (Gaussian on the register index), masked by relu(z) > 0
         f32x16 dd = zero_acc();
+        if (a.ablate & 64) { dd[0] = gs[c * LDG + h]; } else   // (timing experiment: no g_y . W3 products)
         if constexpr (WIDE) {
             // operands of 8 k-steps are read from LDS together, then the 8 (dependent) MFMAs run back to back
 #pragma unroll
@@ -2936,6 +2933,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         }
         WG_MARK(5);
+        if (a.ablate & 32) return;   // (timing experiment: no dW3)
         if constexpr (WIDE) {
             // dW3 = g_y^T relu(z): A = g_y columns, B = relu(z) columns of this wave's feature tile, gathered over the k-step's rows
 #pragma unroll
@@ -2983,6 +2981,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int i = 0; i < 8; i++) a.timing[wave * 8 + i] = i < 7 ? tph[i] : (unsigned long long)nslab;
     }
 #undef WG_MARK
+    if (a.ablate & 16) return;   // (timing experiment: no flush)
     // flush: dW2[m = 32 w + row][n = 32 u + column]
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -3020,6 +3019,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (gcol + 8 * i < nk) atomicAdd(&gs[gcol + 8 * i], bsum3[i]);
     __syncthreads();
     if (tid < nk) atomicAdd(J.db3 + tid, gs[tid]);
+}
+
+#define ED3_WGRAD_TR_LDS(WIDE_)                                                                                                   \
+    __shared__ float zbuf0[32 * HJ_W];                                                                                            \
+    __shared__ float zbuf1[32 * HJ_W];                                                                                            \
+    __shared__ float astage[(WIDE_) ? 32 * HJ_W : 4];                                                                             \
+    __shared__ __attribute__((aligned(256))) char aimg[24576];   /* piece image of the a slab */                                  \
+    __shared__ float gs[32 * ((WIDE_) ? 49 : 5)];                                                                                 \
+    __shared__ int rid0[32];   /* Gaussian ids of a slab's 32 rows (two slabs: one being fetched, one in use); */                 \
+    __shared__ int rid1[32];   /* separate objects, like the z buffers */
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_head_wgrad_tr_kernel(HeadWgradArgs a)
+{
+    ED3_WGRAD_TR_LDS(WIDE)
+    head_wgrad_tr_body<WIDE>(a, (int)blockIdx.x, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
+}
+
+// Both kinds in ONE launch (default; ED3DGS_WGRAD_SEPARATE=1 for the two launches): the SH head's blocks first, then the narrow
+// heads'.  A block ends by adding its 90-KB partial result into the job's matrices, and the memory side executes those adds at
+// ~1.1 TB/s: with 512 blocks finishing together that is a 46-us tail of the SH head's launch in which the chip only waits
+// (ED3DGS_WG_ABLATE=16, round 4: 0.141 -> 0.096 ms without the adds; walking the matrices from a block-dependent position changed
+// nothing -- it is the volume, not the order).  In one launch the narrow heads' blocks compute while the SH head's adds drain.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+deform_head_wgrad_tr_all_kernel(HeadWgradArgs aw, HeadWgradArgs an, int n_wide_blocks)
+{
+    ED3_WGRAD_TR_LDS(true)
+    if ((int)blockIdx.x < n_wide_blocks) head_wgrad_tr_body<true>(aw, (int)blockIdx.x, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
+    else head_wgrad_tr_body<false>(an, (int)blockIdx.x - n_wide_blocks, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
 }
 
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
@@ -4065,22 +4093,38 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3(nblk), dim3(256), wg_lds, s, wa);
     }
     if (pw5) prof_stop(ED3DGS_PROF_DEFORM_WGRAD_TRUNK, s);
-    // narrow heads and the wide head are separate launches (separate register allocations); each launch spreads its
-    // jobs over ~2 blocks per CU
-    for (int wide = 0; wide < 2; wide++) {
-        HeadWgradArgs ha;
+    // each kind of head job (narrow / the wide SH head) spreads its jobs over ~2 blocks per CU
+    auto head_args = [&](HeadWgradArgs &ha, bool wide) {   // the jobs of one kind and their blocks; returns the number of blocks
         std::memset(&ha, 0, sizeof ha);
         ha.P = cfg->P;
         ha.rows = d.rows; ha.n_act = d.n_act;
         for (const HeadJob &J : hjobs)
-            if ((J.nk > 4) == (wide != 0)) ha.job[ha.njobs++] = J;
-        if (!ha.njobs) continue;
+            if ((J.nk > 4) == wide) ha.job[ha.njobs++] = J;
         int nblk = 0;
         for (int q = 0; q < ha.njobs; q++) {
             ha.blk_begin[q] = nblk;
             nblk += std::max(1, std::min((cfg->P + 127) / 128, 512 / ha.njobs));
         }
         ha.blk_begin[ha.njobs] = nblk;
+        ha.ablate = opt(OPT_WG_ABLATE);
+        return nblk;
+    };
+    bool heads_done = false;
+    if (fwd_pieces(cfg) == 3 && cfg->P < (1 << 23) && !opt(OPT_WGRAD_SEPARATE) && !opt(OPT_WG_TIMING)) {
+        // exact three-piece mode: ONE launch, the SH head's blocks in front of the narrow heads' (deform_head_wgrad_tr_all_kernel)
+        HeadWgradArgs hw, hn;
+        const int nbw = head_args(hw, true), nbn = head_args(hn, false);
+        if (hw.njobs && hn.njobs) {
+            const bool ps = prof_start(ED3DGS_PROF_DEFORM_WGRAD_NARROW, s);
+            hipLaunchKernelGGL(deform_head_wgrad_tr_all_kernel, dim3(nbw + nbn), dim3(256), 0, s, hw, hn, nbw);
+            if (ps) prof_stop(ED3DGS_PROF_DEFORM_WGRAD_NARROW, s);
+            heads_done = true;
+        }
+    }
+    for (int wide = 0; wide < 2 && !heads_done; wide++) {
+        HeadWgradArgs ha;
+        const int nblk = head_args(ha, wide != 0);
+        if (!ha.njobs) continue;
         const size_t lds = (size_t)(2 * 32 * HJ_W + 32 * 65 + (wide ? 48 * HJ_W : 0)) * sizeof(float);  // z, a, g_y slabs (+ W3)
         const bool b3 = use_b3(cfg);
         const int sub = wide ? ED3DGS_PROF_DEFORM_WGRAD_WIDE : ED3DGS_PROF_DEFORM_WGRAD_NARROW;
@@ -4090,13 +4134,16 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
             static unsigned long long *wg_timing = nullptr;
             if (opt(OPT_WG_TIMING) && !wg_timing) (void)hipMalloc((void **)&wg_timing, 2 * 32 * sizeof(unsigned long long));
             ha.timing = opt(OPT_WG_TIMING) ? wg_timing + 32 * wide : nullptr;
-            ha.ablate = opt(OPT_WG_ABLATE);
             if (wide) hipLaunchKernelGGL(deform_head_wgrad_tr_kernel<true>, dim3(nblk), dim3(256), 0, s, ha);   // static LDS: 80 KB / 74 KB
             else hipLaunchKernelGGL(deform_head_wgrad_tr_kernel<false>, dim3(nblk), dim3(256), 0, s, ha);
             if (ha.timing) {   // diagnostic: phase cycle sums of block 0 (0 S1 wait, 1 store_g + split, 2 S2 wait, 3 DMA issue, 4 g_z, 5 dW2, 6 dW3)
                 unsigned long long t[32];
                 (void)hipStreamSynchronize(s);
                 (void)hipMemcpy(t, ha.timing, sizeof t, hipMemcpyDeviceToHost);
+                int occ = -1;
+                if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, deform_head_wgrad_tr_kernel<true>, 256, 0);
+                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, deform_head_wgrad_tr_kernel<false>, 256, 0);
+                fprintf(stderr, "[ed3dgs] wgrad_tr<%d>: %d blocks in the launch, %d resident per CU\n", wide, nblk, occ);
                 for (int wv = 0; wv < 4; wv++) {
                     fprintf(stderr, "[ed3dgs] wgrad_tr<%d> wave %d, %llu slabs, cycles/slab:", wide, wv, t[wv * 8 + 7]);
                     for (int i = 0; i < 7; i++) fprintf(stderr, " %llu", t[wv * 8 + i] / (t[wv * 8 + 7] ? t[wv * 8 + 7] : 1));
