@@ -3021,6 +3021,85 @@ __device__ __forceinline__ void head_wgrad_tr_body(const HeadWgradArgs &a, const
     if (tid < nk) atomicAdd(J.db3 + tid, gs[tid]);
 }
 
+// (the per-frame part of the backward: here, in front of the one-launch head kernel that carries its blocks)
+struct FrameBwdArgs {
+    int W, E, TD, max_emb, num_offsets, cam_no;
+    int use_stage[2];
+    const float *params[2];
+    float *gparams[2];
+    size_t W1_off, b1_off;
+    const float *fs, *offsets;
+    float *g_table, *g_offsets;
+};
+// block (bx, s) of (ceil(TD / 64), 2 stages); thread (jj, og) owns column j = 64 bx + jj and rows o = og (mod 4); s_gh: 256 floats of LDS
+__device__ __forceinline__ void deform_frame_bwd_body(const FrameBwdArgs &a, const int bx, const int s, float (*s_gh)[64])
+{
+    if (!a.use_stage[s]) return;
+    const int TD = a.TD, ld = TD + a.E;
+    const int jj = threadIdx.x & 63, og = threadIdx.x >> 6;
+    const int j = bx * 64 + jj;
+    const float *fs = a.fs + (size_t)s * FS_STRIDE;
+    const float *__restrict__ W1 = a.params[s] + a.W1_off;
+    float *__restrict__ dW1 = a.gparams[s] + a.W1_off;
+    const float *__restrict__ ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
+    float gh = 0.f;
+    if (j < TD) {
+        const float hj = fs[j];
+        // 8 rows per trip: the loads of a trip are issued together (one memory latency per trip, not per row)
+        for (int o0 = og; o0 < a.W; o0 += 32) {
+            float gb[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int o = min(o0 + 4 * u, a.W - 1);
+                gb[u] = ghb[o];
+                wv[u] = W1[(size_t)o * ld + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int o = o0 + 4 * u;
+                if (o < a.W) {
+                    dW1[(size_t)o * ld + j] = gb[u] * hj;
+                    gh += wv[u] * gb[u];
+                }
+            }
+        }
+    }
+    s_gh[og][jj] = gh;
+    __syncthreads();
+    float gt = 0.f;
+    if (og == 0 && j < TD) {
+        gh = s_gh[0][jj] + s_gh[1][jj] + s_gh[2][jj] + s_gh[3][jj];
+        for (int q = 0; q < 4; q++) {
+            const int row = __float_as_int(fs[2 * TD + q]);
+            atomicAdd(a.g_table + (size_t)row * TD + j, fs[2 * TD + 4 + q] * gh);
+        }
+        gt = gh * fs[TD + j];
+    }
+    for (int off = 32; off >= 1; off >>= 1) gt += __shfl_xor(gt, off);
+    if (og == 0) {  // wave 0: every lane holds the block's dL/dt partial
+        if (a.cam_no >= 0) {
+            if (jj == 0) atomicAdd(a.g_offsets + a.cam_no, gt);
+        } else {  // mean over the non-zero offsets: each of them receives gt / count
+            for (int base = 0; base < a.num_offsets; base += 64) {
+                const int i = base + jj;
+                const bool nz = i < a.num_offsets && a.offsets[i] != 0.f;
+                int cnt = 0;
+                for (int b2 = 0; b2 < a.num_offsets; b2 += 64) {
+                    const int i2 = b2 + jj;
+                    cnt += __popcll(__ballot(i2 < a.num_offsets && a.offsets[i2] != 0.f));
+                }
+                if (nz) atomicAdd(a.g_offsets + i, gt / (float)cnt);
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) deform_frame_bwd_kernel(FrameBwdArgs a)
+{
+    __shared__ float s_gh[4][64];
+    deform_frame_bwd_body(a, (int)blockIdx.x, (int)blockIdx.y, s_gh);
+}
+
+
 #define ED3_WGRAD_TR_LDS(WIDE_)                                                                                                   \
     __shared__ float zbuf0[32 * HJ_W];                                                                                            \
     __shared__ float zbuf1[32 * HJ_W];                                                                                            \
@@ -3042,12 +3121,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // ~1.1 TB/s: with 512 blocks finishing together that is a 46-us tail of the SH head's launch in which the chip only waits
 // (ED3DGS_WG_ABLATE=16, round 4: 0.141 -> 0.096 ms without the adds; walking the matrices from a block-dependent position changed
 // nothing -- it is the volume, not the order).  In one launch the narrow heads' blocks compute while the SH head's adds drain.
+// The launch's first blocks are the per-frame backward (deform_frame_bwd_body: 8 blocks at TD = 256; it needs db1 of the dW1 launch
+// in front of this one and nothing of this one): a 9-us launch of its own otherwise, a latency chain on eight CUs.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-deform_head_wgrad_tr_all_kernel(HeadWgradArgs aw, HeadWgradArgs an, int n_wide_blocks)
+deform_head_wgrad_tr_all_kernel(HeadWgradArgs aw, HeadWgradArgs an, int n_wide_blocks, FrameBwdArgs fa, int n_frame_x)
 {
     ED3_WGRAD_TR_LDS(true)
-    if ((int)blockIdx.x < n_wide_blocks) head_wgrad_tr_body<true>(aw, (int)blockIdx.x, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
-    else head_wgrad_tr_body<false>(an, (int)blockIdx.x - n_wide_blocks, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
+    const int b = (int)blockIdx.x - 2 * n_frame_x;
+    if (b < 0) deform_frame_bwd_body(fa, (int)blockIdx.x % n_frame_x, (int)blockIdx.x / n_frame_x, reinterpret_cast<float (*)[64]>(gs));
+    else if (b < n_wide_blocks) head_wgrad_tr_body<true>(aw, b, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
+    else head_wgrad_tr_body<false>(an, b - n_wide_blocks, zbuf0, zbuf1, astage, aimg, gs, rid0, rid1);
 }
 
 // two instantiations (narrow heads nk <= 4 / the 48-wide rgb head) so that each gets its own register allocation
@@ -3452,82 +3535,6 @@ __global__ void __launch_bounds__(256) deform_prep_kernel(PrepArgs p)
     if (bx < p.nb[6] && by == 0) deform_active_rows_body(p.aa, bx);
 }
 
-struct FrameBwdArgs {
-    int W, E, TD, max_emb, num_offsets, cam_no;
-    int use_stage[2];
-    const float *params[2];
-    float *gparams[2];
-    size_t W1_off, b1_off;
-    const float *fs, *offsets;
-    float *g_table, *g_offsets;
-};
-// grid = (ceil(TD / 64), 2 stages); thread (jj, og) owns column j = 64*blockIdx.x + jj and rows o = og (mod 4)
-__global__ void __launch_bounds__(256) deform_frame_bwd_kernel(FrameBwdArgs a)
-{
-    const int s = blockIdx.y;
-    if (!a.use_stage[s]) return;
-    __shared__ float s_gh[4][64];
-    __shared__ float s_gt[4];
-    const int TD = a.TD, ld = TD + a.E;
-    const int jj = threadIdx.x & 63, og = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + jj;
-    const float *fs = a.fs + (size_t)s * FS_STRIDE;
-    const float *__restrict__ W1 = a.params[s] + a.W1_off;
-    float *__restrict__ dW1 = a.gparams[s] + a.W1_off;
-    const float *__restrict__ ghb = a.gparams[s] + a.b1_off;  // db1 = column sum of g_hid, already reduced
-    float gh = 0.f;
-    if (j < TD) {
-        const float hj = fs[j];
-        // 8 rows per trip: the loads of a trip are issued together (one memory latency per trip, not per row)
-        for (int o0 = og; o0 < a.W; o0 += 32) {
-            float gb[8], wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int o = min(o0 + 4 * u, a.W - 1);
-                gb[u] = ghb[o];
-                wv[u] = W1[(size_t)o * ld + j];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int o = o0 + 4 * u;
-                if (o < a.W) {
-                    dW1[(size_t)o * ld + j] = gb[u] * hj;
-                    gh += wv[u] * gb[u];
-                }
-            }
-        }
-    }
-    s_gh[og][jj] = gh;
-    __syncthreads();
-    float gt = 0.f;
-    if (og == 0 && j < TD) {
-        gh = s_gh[0][jj] + s_gh[1][jj] + s_gh[2][jj] + s_gh[3][jj];
-        for (int q = 0; q < 4; q++) {
-            const int row = __float_as_int(fs[2 * TD + q]);
-            atomicAdd(a.g_table + (size_t)row * TD + j, fs[2 * TD + 4 + q] * gh);
-        }
-        gt = gh * fs[TD + j];
-    }
-    for (int off = 32; off >= 1; off >>= 1) gt += __shfl_xor(gt, off);
-    if (og == 0) {  // wave 0: every lane holds the block's dL/dt partial
-        if (a.cam_no >= 0) {
-            if (jj == 0) atomicAdd(a.g_offsets + a.cam_no, gt);
-        } else {  // mean over the non-zero offsets: each of them receives gt / count
-            for (int base = 0; base < a.num_offsets; base += 64) {
-                const int i = base + jj;
-                const bool nz = i < a.num_offsets && a.offsets[i] != 0.f;
-                int cnt = 0;
-                for (int b2 = 0; b2 < a.num_offsets; b2 += 64) {
-                    const int i2 = b2 + jj;
-                    cnt += __popcll(__ballot(i2 < a.num_offsets && a.offsets[i2] != 0.f));
-                }
-                if (nz) atomicAdd(a.g_offsets + i, gt / (float)cnt);
-            }
-        }
-    }
-    (void)s_gt;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
@@ -3861,6 +3868,7 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
     for (int s = 0; s < 2; s++) if (cfg->use_stage[s] && (!params[s] || !gparams[s])) { set_error("ed3dgs_deform_backward: null params"); return ED3DGS_ERR_INVALID; }
     if (workspace_bytes < carve(cfg, true, nullptr, nullptr)) { set_error("ed3dgs_deform_backward: workspace too small"); return ED3DGS_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
+    bool frame_done = false;   // the per-frame backward rode along in the head weight-gradient launch
     const ParamLayout pl = param_layout(cfg->W, cfg->TD, cfg->E, cfg->n_sh, cfg->D);
     ZeroArgs za;   // the accumulated outputs start from zero: part of the prepare launch (its own launch only when P == 0)
     za.p[0] = g_table; za.n[0] = (size_t)cfg->max_embeddings * cfg->TD;
@@ -4103,12 +4111,19 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
         int nblk = 0;
         for (int q = 0; q < ha.njobs; q++) {
             ha.blk_begin[q] = nblk;
-            nblk += std::max(1, std::min((cfg->P + 127) / 128, 512 / ha.njobs));
+            const int target = opt(wide ? OPT_WG_BLOCKS_WIDE : OPT_WG_BLOCKS_NARROW) > 0 ? opt(wide ? OPT_WG_BLOCKS_WIDE : OPT_WG_BLOCKS_NARROW) : 512;
+            nblk += std::max(1, std::min((cfg->P + 127) / 128, target / ha.njobs));
         }
         ha.blk_begin[ha.njobs] = nblk;
         ha.ablate = opt(OPT_WG_ABLATE);
         return nblk;
     };
+    FrameBwdArgs fb;
+    fb.W = cfg->W; fb.E = cfg->E; fb.TD = cfg->TD; fb.max_emb = cfg->max_embeddings; fb.num_offsets = cfg->num_offsets;
+    fb.cam_no = cfg->cam_no; fb.W1_off = pl.W1; fb.b1_off = pl.b1; fb.fs = w.fs; fb.offsets = offsets;
+    fb.g_table = g_table; fb.g_offsets = g_offsets;
+    for (int st = 0; st < 2; st++) { fb.use_stage[st] = cfg->use_stage[st]; fb.params[st] = params[st]; fb.gparams[st] = gparams[st]; }
+    const int n_frame_x = (cfg->TD + 63) / 64;
     bool heads_done = false;
     if (fwd_pieces(cfg) == 3 && cfg->P < (1 << 23) && !opt(OPT_WGRAD_SEPARATE) && !opt(OPT_WG_TIMING)) {
         // exact three-piece mode: ONE launch, the SH head's blocks in front of the narrow heads' (deform_head_wgrad_tr_all_kernel)
@@ -4116,9 +4131,9 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
         const int nbw = head_args(hw, true), nbn = head_args(hn, false);
         if (hw.njobs && hn.njobs) {
             const bool ps = prof_start(ED3DGS_PROF_DEFORM_WGRAD_NARROW, s);
-            hipLaunchKernelGGL(deform_head_wgrad_tr_all_kernel, dim3(nbw + nbn), dim3(256), 0, s, hw, hn, nbw);
+            hipLaunchKernelGGL(deform_head_wgrad_tr_all_kernel, dim3(2 * n_frame_x + nbw + nbn), dim3(256), 0, s, hw, hn, nbw, fb, n_frame_x);
             if (ps) prof_stop(ED3DGS_PROF_DEFORM_WGRAD_NARROW, s);
-            heads_done = true;
+            heads_done = frame_done = true;
         }
     }
     for (int wide = 0; wide < 2 && !heads_done; wide++) {
@@ -4173,6 +4188,7 @@ static int deform_backward_impl(const ed3dgs_deform_cfg *cfg, const float *table
     if (!check_hip(hipGetLastError(), "deform wgrad")) return ED3DGS_ERR_HIP;
 
     }
+    if (frame_done) return 0;
     FrameBwdArgs fb;
     fb.W = cfg->W; fb.E = cfg->E; fb.TD = cfg->TD; fb.max_emb = cfg->max_embeddings; fb.num_offsets = cfg->num_offsets;
     fb.cam_no = cfg->cam_no; fb.W1_off = pl.W1; fb.b1_off = pl.b1; fb.fs = w.fs; fb.offsets = offsets;

@@ -120,10 +120,14 @@ def test_golden_values_and_grads(path, mode, monkeypatch, libopt):
     (65836, 128, True, dict(sparse=0.6)), (70001, 128, True, dict(sparse=0.97, no_dr=True)), (5000, 128, True, dict(sparse=-1)),
     (5000, 128, True, dict(sparse=1.0)), (65836, 128, True, dict(sparse=0.6, dense_bwd=True)),
     (65836, 128, True, dict(sparse=0.6, no_coarse_deform=True)),
+    # the head weight gradients + the per-frame backward as separate launches (ED3DGS_WGRAD_SEPARATE=1; default: one launch,
+    # which every case above runs)
+    (65836, 128, True, dict(separate_wgrad=True)), (5000, 128, True, dict(sparse=0.6, separate_wgrad=True)),
 ], ids=["5k", "5k-stateless", "w64", "tail", "tail-no_dr-no_dc", "tail-fine-only-no_ds", "tail-coarse-only-stateless",
         "5k-split-bf16", "tail-split-bf16-no_dr", "w64-split-bf16",
         "5k-fp32-mfma", "5k-stateless-fp32-mfma", "tail-fp32-mfma-no_dr", "w64-fp32-mfma",
-        "sparse60", "sparse97-no_dr", "one-active-row", "no-active-row", "sparse60-dense-walk", "sparse60-fine-only"])
+        "sparse60", "sparse97-no_dr", "one-active-row", "no-active-row", "sparse60-dense-walk", "sparse60-fine-only",
+        "tail-wgrad-launches-separate", "5k-sparse60-wgrad-launches-separate"])
 def test_against_torch_restatement(P, W, keep, flags, monkeypatch, libopt):
     """keep=True: the forward keeps the hidden activations for the backward (width 128; other widths re-form them);
     keep=False: the stateless backward that re-forms them.  Both against the float64 restatement."""
@@ -139,6 +143,7 @@ def test_against_torch_restatement(P, W, keep, flags, monkeypatch, libopt):
     if flags.pop("f32", False):
         libopt("DEFORM_FP32_MFMA", 1)
     sparse = flags.pop("sparse", 0.0)
+    libopt("WGRAD_SEPARATE", 1 if flags.pop("separate_wgrad", False) else 0)
     libopt("DEFORM_DENSE_BWD", 0)
     if flags.pop("dense_bwd", False):
         libopt("DEFORM_DENSE_BWD", 1)

@@ -4,7 +4,7 @@ usage: python tools/step_gaps.py gpurun_out/<dir>"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if "deform_frame_bwd_kernel" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "deform_frame_bwd_kernel" in r["Kernel_Name"] or "deform_head_wgrad_tr_all_kernel" in r["Kernel_Name"]]   # a step's last launch
 prev_end_t = None
 for n in range(1, len(ends)):
     sel = rows[ends[n - 1] + 1:ends[n] + 1]

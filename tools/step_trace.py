@@ -5,7 +5,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a forward+backward step: from the deform_frag_kernel before a render_forward to the deform_frame_bwd_kernel after the render_backward
-ends = [i for i, r in enumerate(rows) if "deform_frame_bwd_kernel" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "deform_frame_bwd_kernel" in r["Kernel_Name"] or "deform_head_wgrad_tr_all_kernel" in r["Kernel_Name"]]   # a step's last launch
 e = ends[-back]
 prev = ends[-back - 1]
 sel = rows[prev + 1:e + 1]
