@@ -410,7 +410,10 @@ __device__ __forceinline__ void preprocess_backward_body(
 // lane stride.  The live rows are staged in LDS (odd row stride: conflict-free) and written out row by row, coalesced within
 // a row; the dead rows are zeroed by the whole block as one stream with holes.
 // (153 registers = 3 waves per SIMD; asking the allocator for 4 / 5 waves spills and loses, round 3.)
-constexpr int KB_ROWS = 512;
+#ifndef ED3_K89_ROWS
+#define ED3_K89_ROWS 512   // a multiple of 256
+#endif
+constexpr int KB_ROWS = ED3_K89_ROWS;
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     int P, int D, int M, const float *__restrict__ means, const int *__restrict__ radii, const float *__restrict__ shs,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
