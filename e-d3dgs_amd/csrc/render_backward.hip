@@ -63,6 +63,63 @@ __device__ __forceinline__ void row_transpose_reduce(float (&v)[NV], int lane, f
     }
 }
 
+// The same reduction with the two 16-lane-rotation steps FIRST, where a step has 8 and 4 results: a rotation step selects by a bank
+// bit of the lane ((lane & 4), (lane & 8); a DPP bank = 4 lanes), so "keep one value, send the other" needs no select at all --
+// v_add_f32_dpp with bank_mask writes the sum of value 2i into the banks that keep it and the sum of value 2i+1 into the others:
+// 2 instructions per result instead of 3 (2 v_cndmask + 1 add).  row_ror:4 has to come before row_ror:8: a rotation by 4 pairs bank
+// k with bank k-1, whose (lane & 8) differs for two of the four banks, so it must read values no bank bit has selected yet; the
+// rotation by 8 then pairs banks with equal (lane & 4).  The quad_perm steps select by a lane bit inside a bank and keep the select
+// form.  24 + 6 + 3 = 33 instructions per 16 values instead of 45.  On return lane l holds value (l & 15) as before: the caller's
+// values enter in the order the steps' bit selection undoes (value k at position (k>>2 & 1) | (k>>3 & 1) << 1 | (k>>1 & 1) << 2 |
+// (k & 1) << 3).  Inline assembly: the compiler has no builtin for a DPP add with a bank mask (update_dpp + add would be 3 again);
+// the s_nop in front covers "VALU write -> DPP read" (2 wait states) for the inputs, the one behind for the compiler's next DPP.
+#ifndef ED3_K7_BANK_REDUCE
+#define ED3_K7_BANK_REDUCE 1
+#endif
+__device__ __forceinline__ float row_transpose_reduce16_banks(const float (&v)[16], int lane)
+{
+    constexpr int pos[16] = {0, 8, 4, 12, 1, 9, 5, 13, 2, 10, 6, 14, 3, 11, 7, 15};   // pos[k]: where value k enters
+    float u[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) u[pos[k]] = v[k];
+    float a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %12, %12 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %14, %14 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %16, %16 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %17, %17 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %18, %18 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %19, %19 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %21, %21 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %22, %22 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %23, %23 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %24, %24 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %25, %25 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %26, %26 row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %27, %27 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %8, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %9, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %9, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %10, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %10, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %11, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %11, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7),
+          "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]),
+          "v"(u[8]), "v"(u[9]), "v"(u[10]), "v"(u[11]), "v"(u[12]), "v"(u[13]), "v"(u[14]), "v"(u[15]));
+    const bool l1 = lane & 2, l0 = lane & 1;
+    const float c0 = (l1 ? b1 : b0) + dpp_mov<0x4E>(l1 ? b0 : b1);   // quad_perm [2,3,0,1]
+    const float c1 = (l1 ? b3 : b2) + dpp_mov<0x4E>(l1 ? b2 : b3);
+    return (l0 ? c1 : c0) + dpp_mov<0xB1>(l0 ? c0 : c1);             // quad_perm [1,0,3,2]
+}
+
 // waves per SIMD asked of the allocator for the headline instantiation (0 = its own choice: 140 registers, 3 waves).  Round 3:
 // 4 waves (128 registers, 52 B of scratch per lane) measured 0.460 against 0.438 ms (tools/ab_build.sh k7w4 -DED3_K7_WAVES=4).
 #ifndef ED3_K7_WAVES
@@ -435,7 +492,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             // ED3_K7_LDS_TILE: the row goes to the entry's row of the LDS tile (ds_add_f32, no return value; quadrants that meet
             // on one entry in the same iteration are serialised by the LDS)
             float z[NV / 16];
+#if ED3_K7_BANK_REDUCE
+            {
+                float lo[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) lo[i] = acc[i];
+                z[0] = row_transpose_reduce16_banks(lo, lane);
+                if (NV == 32) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) lo[i] = acc[(NV - 16) + i];
+                    z[NV / 16 - 1] = row_transpose_reduce16_banks(lo, lane);
+                }
+            }
+#else
             row_transpose_reduce<NV>(acc, lane, z);
+#endif
             const bool qany = (anyb >> (16 * myq) & 0xFFFFull) != 0ull;
 #if ED3_K7_LDS_TILE
             if (act && qany) {
