@@ -280,7 +280,7 @@ def percentiles(v):
     return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "min": v[0], "max": v[-1], "n": len(v)}
 
 
-def rehearse(a, D):
+def rehearse(a, D, emit):
     """Launcher rehearsal (no GPU, no measurement): every piece of the multi-rank harness around a stub step."""
     import torch.distributed as dist
     rank, world, local = D.init()
@@ -310,7 +310,7 @@ def rehearse(a, D):
     cams = sorted({D.item_of(i, wl["cams"], wl["frames"])[0] for i in items})
     ncams = D.gather_per_rank(len(cams), "cpu")
     if rank == 0:
-        print(json.dumps({"metric": "REHEARSAL of the launcher (stub step, no GPU work) -- not a measurement", "value": None,
+        emit(({"metric": "REHEARSAL of the launcher (stub step, no GPU work) -- not a measurement", "value": None,
                           "rehearsal": True, "n_gpus": world, "gpus_arg": a.gpus, "steps": a.steps, "warmup": a.warmup,
                           "backend": dist.get_backend() if dist.is_initialized() else None, "items_per_rank": counts.tolist(),
                           "last_step_ranks_counted": float(last[2]), "seconds": dt,
@@ -324,12 +324,23 @@ def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a, sys.argv[1:]))            # nothing above this line touches the GPU
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner on stdout when its
+    # first communicator is created -- seen on the GPU box in round 4 -- and gloo announces its connections): from here on file
+    # descriptor 1 IS stderr, and emit() below writes the JSON line to the real stdout kept aside.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     from ed3dgs_amd import dist as D
     if a.rehearse_launcher:
         env_world = int(os.environ.get("WORLD_SIZE", "1"))
         if a.gpus != env_world:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, env_world))
-        return rehearse(a, D)
+        return rehearse(a, D, emit)
     from ed3dgs_amd import _lib
     # the rank's device is chosen BEFORE the process group exists: RCCL binds a rank to the device that is current when its
     # communicator is created (first collective), and `barrier()` must not run on device 0 for every rank
@@ -750,7 +761,7 @@ def main():
                 except Exception as ex:
                     pts[name] = {"value": None, "error": repr(ex)}
             res["cpu_baseline_points"] = pts
-    print(json.dumps(res))
+    emit(res)
 
 
 if __name__ == "__main__":

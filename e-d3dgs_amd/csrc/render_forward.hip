@@ -52,19 +52,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
     float DP[4], MD[4], N0[4], N1[4], N2[4];
     float CO0[4], CO1[4], CO2[4], MC0[4], MC1[4], MC2[4];
     uint32_t last[4], maxc[4];
-    bool done[4];
+    // "done" lives in the pixel's alpha threshold: +inf once the pixel has terminated (or lies outside the image), so that the
+    // per-pixel validity test below is the reference's own two comparisons and nothing else (alpha is never NaN: v_min_f32 returns
+    // its other operand, 0.99)
+    float amin[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         T[p] = 1.0f; C0[p] = C1[p] = C2[p] = TG[p] = WT[p] = 0.f;
         DP[p] = MD[p] = N0[p] = N1[p] = N2[p] = 0.f;
         CO0[p] = CO1[p] = CO2[p] = MC0[p] = MC1[p] = MC2[p] = 0.f;
         last[p] = 0; maxc[p] = 0xFFFFFFFFu;
-        done[p] = !(p < nvalid);
+        amin[p] = (p < nvalid) ? ALPHA_MIN : __builtin_inff();
     }
+#define ED3_ALL_DONE() (amin[0] == __builtin_inff() && amin[1] == __builtin_inff() && amin[2] == __builtin_inff() && amin[3] == __builtin_inff())
 
     bool finished = false;
     for (int base = 0; base < n && !finished; base += 64) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        if (__all(ED3_ALL_DONE())) break;
         __syncthreads();
         const int k = base + lane;
         unsigned keepq = 0;   // quadrants of the tile in which this lane's entry can reach alpha >= 1/255
@@ -113,8 +117,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
                 dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
                 const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
                 alpha[2 * q] = ap.alpha.x; alpha[2 * q + 1] = ap.alpha.y;
-                valid[2 * q] = act && !done[2 * q] && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
-                valid[2 * q + 1] = act && !done[2 * q + 1] && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
+                valid[2 * q] = act && !(ap.power.x > 0.0f) && !(ap.alpha.x < amin[2 * q]);
+                valid[2 * q + 1] = act && !(ap.power.y > 0.0f) && !(ap.alpha.y < amin[2 * q + 1]);
                 any_valid |= valid[2 * q] | valid[2 * q + 1];
             }
             if (!__any(any_valid)) continue;
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
                 const float test_T = T[p] * (1.0f - alpha[p]);
                 const bool term = valid[p] && (test_T < 0.0001f);
                 const bool blend = valid[p] && !term;
-                done[p] = done[p] || term;
+                amin[p] = term ? __builtin_inff() : amin[p];
                 any_term |= term;
                 const float aT = blend ? alpha[p] * T[p] : 0.0f;
                 C0[p] += r1.z * aT; C1[p] += r1.w * aT; C2[p] += r2.x * aT;
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
                 last[p] = blend ? contributor : last[p];
             }
             if (__any(any_term)) {   // a quadrant whose 64 pixels are all done drops the rest of its sub-list
-                const unsigned long long dn = __ballot(done[0] && done[1] && done[2] && done[3]);
+                const unsigned long long dn = __ballot(ED3_ALL_DONE());
                 if (dn == ~0ull) { finished = true; break; }
                 if ((dn & 0xFFFFull) == 0xFFFFull) live0 = 0ull;
                 if ((dn >> 16 & 0xFFFFull) == 0xFFFFull) live1 = 0ull;

@@ -16,7 +16,7 @@ def init(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("ED3DGS_DIST_COLLECTIVES_AT_WORLD_1") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -25,6 +25,16 @@ def init(backend=None):
             backend = os.environ.get("ED3DGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _active():
+    """True when collectives are to be issued: a process group of more than one rank -- or of ONE rank when
+    ED3DGS_DIST_COLLECTIVES_AT_WORLD_1=1, which is how tests/test_dist_rccl_gpu.py drives every collective of this module through
+    RCCL on a one-GPU box (RCCL refuses two ranks on one device, so a one-rank communicator is the most a single card can show:
+    communicator creation, device-tensor all-reduce, stream-ordered wait())."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("ED3DGS_DIST_COLLECTIVES_AT_WORLD_1") == "1"
 
 
 def _on_wire(t):
@@ -36,7 +46,7 @@ def _on_wire(t):
 
 def allreduce_sum_(t):
     """In-place SUM over ranks of a small tensor (the path's loss/psnr/count vector)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         w = _on_wire(t)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         if w is not t:
@@ -64,7 +74,7 @@ def allreduce_sum_async(t):
     """SUM over ranks of a small tensor, not waited for: the caller waits one step later (bench.py), which takes the
     per-step collective out of the ranks' critical path -- frames differ in cost, and a blocking collective per 4 ms
     step would run every rank at the pace of the slowest frame of each step."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         w = _on_wire(t)
         return _Reduced(t, w, dist.all_reduce(w, op=dist.ReduceOp.SUM, async_op=True))
     return _Reduced(t)
@@ -158,7 +168,7 @@ def allreduce_stats(loss_sum, psnr_sum, count, device):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         if dist.get_backend() == "nccl":   # RCCL: on the rank's own device (the caller selected it before init())
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
@@ -167,7 +177,7 @@ def barrier():
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64 if device == "cpu" else torch.float32, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         w = _on_wire(t)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         t = w
@@ -181,7 +191,7 @@ def allreduce_gradients_(params, bucket_bytes=64 << 20, average=True):
     links streaming and the launch count low; each bucket's collective is issued asynchronously and the copies back wait
     on it, so bucket k+1's packing overlaps bucket k's transfer.  Parameters whose .grad is None contribute zeros (a
     rank whose frame saw nothing of a parameter must still take part in the collective)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not (_active()):
         return
     world = dist.get_world_size()
     params = [p for p in params if p.requires_grad]
@@ -254,7 +264,7 @@ class BucketedGradReducer:
             b = self.buckets[i]
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
             wire = _on_wire(flat)
-            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True) if (dist.is_initialized() and dist.get_world_size() > 1) else None
+            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True) if (_active()) else None
             self.pending[i] = (flat, wire, work)
             self.next_issue += 1
             if not force:
