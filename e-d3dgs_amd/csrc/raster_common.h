@@ -113,7 +113,30 @@ __device__ __forceinline__ float gauss_alpha(float w, float G)
 struct AlphaPair {
     f32x2 power, G, alpha;
 };
-__device__ __forceinline__ AlphaPair alpha_pair(const ConicRow &r, float w, f32x2 dx)
+// The row constants as the packed operands of alpha_pair, formed ONCE per (Gaussian, lane) -- round 4: inside alpha_pair they were
+// formed per pixel pair (the asm statement cannot be merged), four v_mov_b32 per call.
+struct ConicSplat {
+#if ED3_EXACT_ALPHA
+    f32x2 cx2, cy2, t22, dy2;
+#else
+    ConicRow r;
+#endif
+};
+__device__ __forceinline__ ConicSplat conic_splat(const ConicRow &r)
+{
+    ConicSplat o;
+#if ED3_EXACT_ALPHA
+    // explicit splats of values the optimiser cannot trace back to the record's float4 (it otherwise gathers them into a
+    // 4-vector and extracts the register pairs of the packed operands THROUGH SCRATCH MEMORY, inside the blend loop)
+    float cx = r.cx, cy = r.cy, t2 = r.t2, dy = r.dy;
+    asm volatile("" : "+v"(cx), "+v"(cy), "+v"(t2), "+v"(dy));
+    o.cx2 = f32x2{cx, cx}; o.cy2 = f32x2{cy, cy}; o.t22 = f32x2{t2, t2}; o.dy2 = f32x2{dy, dy};
+#else
+    o.r = r;
+#endif
+    return o;
+}
+__device__ __forceinline__ AlphaPair alpha_pair(const ConicSplat &c, float w, f32x2 dx)
 {
 #pragma clang fp contract(off)
     AlphaPair o;
@@ -121,11 +144,7 @@ __device__ __forceinline__ AlphaPair alpha_pair(const ConicRow &r, float w, f32x
     constexpr float L_HI = 1.4426950408889634f;
     constexpr float L_LO = (float)(1.4426950408889634073599 - (double)L_HI);
     constexpr float LN2 = 0.6931471805599453f;
-    // explicit splats of values the optimiser cannot trace back to the record's float4 (it otherwise gathers them into a
-    // 4-vector and extracts the register pairs of the packed operands THROUGH SCRATCH MEMORY, inside the blend loop)
-    float cx = r.cx, cy = r.cy, t2 = r.t2, dy = r.dy;
-    asm volatile("" : "+v"(cx), "+v"(cy), "+v"(t2), "+v"(dy));
-    const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, t22 = {t2, t2}, dy2 = {dy, dy};
+    const f32x2 cx2 = c.cx2, cy2 = c.cy2, t22 = c.t22, dy2 = c.dy2;
     const f32x2 t1 = (cx2 * dx) * dx;
     const f32x2 s = t1 + t22;
     const f32x2 t3 = (cy2 * dx) * dy2;
@@ -136,6 +155,7 @@ __device__ __forceinline__ AlphaPair alpha_pair(const ConicRow &r, float w, f32x
     const f32x2 e = {__builtin_amdgcn_exp2f(hi.x), __builtin_amdgcn_exp2f(hi.y)};
     o.G = __builtin_elementwise_fma(e, lo * LN2, e);
 #else
+    const ConicRow &r = c.r;
     const f32x2 inner = __builtin_elementwise_fma(f32x2{r.a, r.a}, dx, f32x2{r.bdy, r.bdy});
     o.power = __builtin_elementwise_fma(dx, inner, f32x2{r.cdy2, r.cdy2});
     o.G = f32x2{__builtin_amdgcn_exp2f(o.power.x), __builtin_amdgcn_exp2f(o.power.y)};

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
         for (int p = 0; p < 4; p++) {
             const bool in = p < nvalid;
             if (!in) { al[p] = 0.f; lc[p] = 0; mc[p] = 0; g0[p] = g1[p] = g2[p] = gA[p] = 0.f; }
-            last[p] = lc[p]; maxc[p] = mc[p];
+            last[p] = lc[p]; maxc[p] = mc[p] - 1u;   // the median contributor's 0-based list position (0xFFFFFFFF: none)
             T[p] = 1.f - al[p];
             V[p] = T[p] * (bg[0] * g0[p] + bg[1] * g1[p] + bg[2] * g2[p]);
             gT[p] = gMT[p] = gN0[p] = gN1[p] = gN2[p] = 0.f;
@@ -351,11 +351,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             // multiply them by alpha = 0, and a slot nobody staged could hold a NaN)
             const int jany = j0 >= 0 ? j0 : j1 >= 0 ? j1 : j2 >= 0 ? j2 : j3;
             const int j = act ? jsel : jany;
-            const uint32_t k = (uint32_t)(top - 1 - j);  // 0-based position in the tile list
+            // 0-based position in the tile list; an idle quadrant gets a position behind every pixel's last contributor, so that the
+            // per-pixel test below needs no separate "quadrant has an entry" term (round 4: the && chain compiled to four
+            // s_and_saveexec / s_or exec pairs per iteration)
+            const uint32_t k = act ? (uint32_t)(top - 1 - j) : 0xFFFFFFFFu;
             const float4 r0 = s_rec[j * 4 + 0];          // x, y, cx, cy
             const float4 r1 = s_rec[j * 4 + 1];          // cz, w, r, g
             const float dy = r0.y - fpy;
             const ConicRow cr = conic_row(r0.z, r0.w, r1.x, dy);
+            const ConicSplat cs = conic_splat(cr);
             // skip decisions in scalars, bit-identical to the forward's; a skipped pixel continues with alpha = G = 0,
             // which makes every update below the identity and every contribution an exact zero (no selects needed)
             float dx[4], alpha[4], G[4];
@@ -364,13 +368,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
 #pragma unroll
             for (int q = 0; q < 2; q++) {   // pixel pairs: the same packed evaluation as the forward's (raster_common.h)
                 dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
-                const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
-                const bool v0 = act && (k < last[2 * q]) && !(ap.power.x > 0.0f) && !(ap.alpha.x < ALPHA_MIN);
-                const bool v1 = act && (k < last[2 * q + 1]) && !(ap.power.y > 0.0f) && !(ap.alpha.y < ALPHA_MIN);
+                const AlphaPair ap = alpha_pair(cs, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
+                const bool v0 = (k < last[2 * q]) & !(ap.power.x > 0.0f) & !(ap.alpha.x < ALPHA_MIN);
+                const bool v1 = (k < last[2 * q + 1]) & !(ap.power.y > 0.0f) & !(ap.alpha.y < ALPHA_MIN);
                 any_valid |= v0 | v1;
                 alpha[2 * q] = v0 ? ap.alpha.x : 0.f; alpha[2 * q + 1] = v1 ? ap.alpha.y : 0.f;
                 G[2 * q] = v0 ? ap.G.x : 0.f; G[2 * q + 1] = v1 ? ap.G.y : 0.f;
-                med[2 * q] = v0 && (k + 1u == maxc[2 * q]); med[2 * q + 1] = v1 && (k + 1u == maxc[2 * q + 1]);
+                med[2 * q] = v0 & (k == maxc[2 * q]); med[2 * q + 1] = v1 & (k == maxc[2 * q + 1]);   // (maxc holds the 0-based position)
             }
             const unsigned long long anyb = __ballot(any_valid);
             if (!anyb) continue;

@@ -109,16 +109,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((!COOR
             const float4 r1 = s_rec[j * 4 + 1];  // cz, w, r, g
             const float dy = r0.y - fpy;
             const ConicRow cr = conic_row(r0.z, r0.w, r1.x, dy);
+            const ConicSplat cs = conic_splat(cr);
             float dx[4], alpha[4];
+            const float op_eff = act ? r1.y : 0.f;
             bool valid[4];
             bool any_valid = false;
 #pragma unroll
             for (int q = 0; q < 2; q++) {   // pixel pairs: the alpha evaluation issues as packed fp32 (raster_common.h)
                 dx[2 * q] = r0.x - fpx[2 * q]; dx[2 * q + 1] = r0.x - fpx[2 * q + 1];
-                const AlphaPair ap = alpha_pair(cr, r1.y, f32x2{dx[2 * q], dx[2 * q + 1]});
+                // (an idle quadrant evaluates the finite record it re-reads with opacity 0: alpha = 0 fails the threshold test, so the
+                // per-pixel test carries no "quadrant has an entry" term)
+                const AlphaPair ap = alpha_pair(cs, op_eff, f32x2{dx[2 * q], dx[2 * q + 1]});
                 alpha[2 * q] = ap.alpha.x; alpha[2 * q + 1] = ap.alpha.y;
-                valid[2 * q] = act && !(ap.power.x > 0.0f) && !(ap.alpha.x < amin[2 * q]);
-                valid[2 * q + 1] = act && !(ap.power.y > 0.0f) && !(ap.alpha.y < amin[2 * q + 1]);
+                valid[2 * q] = !(ap.power.x > 0.0f) & !(ap.alpha.x < amin[2 * q]);
+                valid[2 * q + 1] = !(ap.power.y > 0.0f) & !(ap.alpha.y < amin[2 * q + 1]);
                 any_valid |= valid[2 * q] | valid[2 * q + 1];
             }
             if (!__any(any_valid)) continue;
