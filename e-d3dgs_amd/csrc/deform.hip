@@ -1077,6 +1077,13 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
 #ifndef ED3_FWD_ROT
 #define ED3_FWD_ROT 2
 #endif
+#ifndef ED3_FWD_PIECE_SPREAD
+#define ED3_FWD_PIECE_SPREAD 0   // 1: head tiles of the forward issue the next chunk's LDS-DMA pieces one per 8-MFMA step instead of three per
+                                 // k-tile (round 2).  Measured in round 4 (same box, three rounds): forward 0.5045 -> 0.5108 ms -- NOT kept
+#endif
+#ifndef ED3_DGRAD_PIECE_SPREAD
+#define ED3_DGRAD_PIECE_SPREAD 0   // ... and in the data gradient's g_a tiles (off with it)
+#endif
 #ifndef ED3_DGRAD_ROT
 #define ED3_DGRAD_ROT 1   // the same rotation (counted waits) in the data gradient's g_a tiles; 0: the plain form
 #endif
@@ -1126,8 +1133,14 @@ typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
                 ACC_ = ED3_MFU(w0_, x1_, ACC_); ACC_ = ED3_MFU(w0_, x0_, ACC_);                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                                               \
                 if (more_) ED3_LDS_READ128(w0_, wa_, ED3_ROT_OFF(kt, st, 0));                                                    \
+                if (ED3_FWD_PIECE_SPREAD) {   /* one LDS-DMA piece per 8-MFMA step (the rest behind the last step) */           \
+                    __builtin_amdgcn_sched_barrier(0);                                                                           \
+                    GPIPE_PIECES(2 * kt + st, 1);                                                                                \
+                    if (2 * kt + st == 2 * NT - 1) GPIPE_PIECES(2 * NT, PIPE_NI - 2 * NT);                                       \
+                    __builtin_amdgcn_sched_barrier(0);                                                                           \
+                }                                                                                                                \
             }                                                                                                                    \
-            GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                                               \
+            if (!ED3_FWD_PIECE_SPREAD) GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                    \
         }                                                                                                                        \
     } else if constexpr (NP == 3 && ED3_FWD_ROT == 1 && ED3_NP3_SMAX == 3) {                                                      \
         const bf16x8 *wq_ = reinterpret_cast<const bf16x8 *>(wb) + lane;                                                         \
@@ -2032,7 +2045,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         ED3_LDS_READ128(w2_, wa_, 2048); ED3_LDS_READ128(w1_, wa_, 1024); ED3_LDS_READ128(w0_, wa_, 0);
 #pragma unroll
                         for (int i2 = 0; i2 < NT; i2++) {
-                            GPIPE_PIECES(i2 * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
+                            if (!ED3_DGRAD_PIECE_SPREAD) GPIPE_PIECES(i2 * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);
 #pragma unroll
                             for (int st = 0; st < 2; st++) {
                                 const bool more_ = 2 * i2 + st + 1 < 2 * NT;
@@ -2052,6 +2065,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 ga[i2] = ED3_MFU(w0_, x1_, ga[i2]); ga[i2] = ED3_MFU(w0_, x0_, ga[i2]);
                                 __builtin_amdgcn_sched_barrier(0);
                                 if (more_) ED3_LDS_READ128(w0_, wa_, ED3_ROT_OFF(i2, st, 0));
+                                if (ED3_DGRAD_PIECE_SPREAD) {   // one LDS-DMA piece per 8-MFMA step (as in the forward's head tiles)
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    GPIPE_PIECES(2 * i2 + st, 1);
+                                    if (2 * i2 + st == 2 * NT - 1) GPIPE_PIECES(2 * NT, PIPE_NI - 2 * NT);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
                             }
                         }
                     } else {
