@@ -443,7 +443,8 @@ def main():
     step.drain()
     torch.cuda.synchronize(); D.barrier()
     log("timed region")
-    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint(1 << dom))
+    # (every third launch of it: 7 of 20 steps, a stride coprime to the camera count; an event pair is ~12 us of idle stream)
+    L.ed3dgs_profile_begin_slots(ctypes.c_int(a.steps + 4), ctypes.c_uint((1 << dom) | (1 << 29)))
     # step-time spread: a mark every MARK_EVERY steps on the launch stream (a mark is a barrier packet too: ~6 us of idle stream,
     # 0.3 % of a step if taken at every boundary)
     MARK_EVERY = a.mark_every if a.mark_every > 0 else (4 if a.steps >= 8 else 1)

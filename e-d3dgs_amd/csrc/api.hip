@@ -121,6 +121,7 @@ struct Profiler {
     int cap = 0;
     unsigned mask = 0;
     int n[ED3DGS_PROF_SLOTS] = {0};
+    int calls[ED3DGS_PROF_SLOTS] = {0};       // launches seen per slot (ED3DGS_PROF_EVERY_3RD times launches 0, 3, 6, ...)
     std::vector<hipEvent_t> e0[ED3DGS_PROF_SLOTS], e1[ED3DGS_PROF_SLOTS];
     unsigned long long *counters = nullptr;   // device: the tile kernels' work counts (see render_backward.hip / render_forward.hip) while their slots are timed
     unsigned long long counters_host[ED3DGS_PROF_COUNTERS] = {0};
@@ -129,6 +130,7 @@ static Profiler g_prof;
 bool prof_start(int slot, hipStream_t s)
 {
     if (!g_prof.on || !(g_prof.mask >> slot & 1u) || g_prof.n[slot] >= g_prof.cap) return false;
+    if ((g_prof.mask & ED3DGS_PROF_EVERY_3RD) && (g_prof.calls[slot]++ % 3) != 0) return false;
     (void)hipEventRecord(g_prof.e0[slot][g_prof.n[slot]], s);
     return true;
 }

@@ -26,7 +26,7 @@ enum { G_R = 0, G_G, G_B, G_TS, G_RPX, G_RPY, G_NX, G_NY, G_NZ, G_MX, G_MY, G_MZ
 // ed3dgs_set_option() -- no entry point reads the environment per call.
 #define ED3_OPTIONS(X) \
     X(BIN_ONE_LEVEL) X(BIN_RADIX) X(BIN_TIMING) X(COUNT_COPY) X(SORT_HANDWRITTEN) \
-    X(DEFORM_BF16X3) X(DEFORM_DENSE_BWD) X(DEFORM_FP32_MFMA) X(DEFORM_NO_TAIL) X(FB_ABLATE) X(FWD_TIMING) X(HOST_TIMING) \
+    X(DEFORM_BF16X3) X(DEFORM_DENSE_BWD) X(DEFORM_FP32_MFMA) X(DEFORM_NO_TAIL) X(FB_ABLATE) X(FWD_PINGPONG) X(FWD_TIMING) X(HOST_TIMING) \
     X(PREP_SEQ) X(STATS_BLOCKS) X(WG_ABLATE) X(WG_BLOCKS_NARROW) X(WG_BLOCKS_WIDE) X(WG_TIMING) X(WGRAD_SEPARATE)
 enum Opt {
 #define X(n) OPT_##n,

@@ -1413,6 +1413,304 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 4: the three-piece forward as an EIGHT-wave block in two TEAMS of four waves that run half a tile apart ("ping-pong").
+// deform_forward_b3_kernel runs two independent 4-wave blocks per CU: each SIMD holds one wave of each, both walk
+// [64 MFMAs | epilogue + kept stores | LDS-DMA issue | barrier] on their own, and a wave's own non-MFMA time (~3 400 of a tile's
+// 5 700 cycles) is covered by its neighbour only when the two happen to be out of phase.  Here the CU holds ONE block; waves w and
+// w + 4 share a SIMD (a workgroup's waves go round the SIMDs) and belong to different teams, and the block's barriers hold the teams
+// exactly one phase apart: while team A runs a tile's MFMAs (the phase that READS the weight chunk), team B runs the previous
+// tile's epilogue (bias, relu, kept stores, sign masks, the 4x4x1 output products) and -- team B only -- issues the LDS-DMA of the
+// chunk after next; at the barrier they swap.  Both teams read the SAME chunk (A in interval 2m, B in 2m + 1), so a CU streams
+// each weight chunk once per 256 Gaussians instead of once per 128, only four of the eight waves ever issue LDS-DMA, and they do
+// it in the phase in which their SIMD's matrix pipe belongs to the other team.  THREE chunk buffers (one block per CU: 111 KB): the
+// second phase of a tile may still read the chunk (the rgb head's output products, the second half of the trunk tiles), so chunk
+// m is live through intervals 2m .. 2m + 2; chunk m + 2 goes into the buffer of chunk m - 1 (last read by B in interval 2m), is issued
+// by B in interval 2m + 2 and waited for (vmcnt(0)) at B's barrier in front of interval 2m + 4.  Every wave executes the same number of barriers: team B one in front (its first
+// interval has no epilogue: it issues chunk 1), team A one behind.  The stage biases of both stages live in LDS for the whole
+// kernel (one block per CU: there is room), so a stage begins with no load and no extra barrier.
+// Per-Gaussian arithmetic, product order and outputs are those of deform_forward_b3_kernel<NT, 3>: bit-identical results
+// (tests/test_deform_parity_gpu.py + tests/test_chain_parity_gpu.py green with ED3DGS_FWD_PINGPONG=1).
+// MEASURED (round 4, same box, three rounds, profiles/r04_fwd_pingpong_ab.md): 0.553 ms against 0.517 ms for the two free-running
+// 4-wave blocks (first version, two buffers and the rgb head / trunk wholly in the first phase: 0.570; teams by bit 0 of the wave
+// index, i.e. both waves of a SIMD in the SAME phase: 0.655 -- so waves w and w + 4 do share a SIMD).  Why it loses: in a strict
+// ping-pong only ONE wave per SIMD issues the 64 dependent 32x32x16 products at a time, and one wave cannot keep the matrix pipe
+// fed (its LDS waits, the s_nop / s_waitcnt between products and the accumulator dependency leave ~1/3 of the slots empty: the
+// probe's one-wave-per-SIMD modes measured 0.58-0.73 of the sustained rate in round 3); two free-running waves fill each other's
+// gaps whenever their product phases overlap, which is most of the time.  A second accumulator per wave would fix the chain, and
+// the kernel has no register left for it.  NOT the default, and not compiled unless -DED3_FWD_PP_KERNEL=1 (tools/ab_build.sh pp
+// -DED3_FWD_PP_KERNEL=1; ED3DGS_FWD_PINGPONG=1 then selects it).
+#ifndef ED3_FWD_PP_KERNEL
+#define ED3_FWD_PP_KERNEL 0
+#endif
+#if ED3_FWD_PP_KERNEL
+#ifndef ED3_FWD_PP_TEAM_BIT
+#define ED3_FWD_PP_TEAM_BIT 2   // team = bit 2 of the wave index (waves w, w + 4 on one SIMD); 0: bit 0 (waves 2i, 2i + 1), for A/B
+#endif
+#define ED3_PP_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define ED3_PP_M_END() do { if (team) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ED3_PP_BAR(); } while (0)
+#define ED3_PP_E_END() do { ED3_PP_BAR(); pipe_n++; } while (0)
+#define ED3_PP_ISSUE()                                                                                                           \
+    do {                                                                                                                         \
+        if (pp_issued < pipe_total) {                                                                                            \
+            const float *gsrc_ = pipe_seq.next(d);                                                                               \
+            float *gdst_ = wl + (pp_issued % 3) * PIPE_CHF;                                                                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < PIPE_NI; i_++)                                                               \
+                __builtin_amdgcn_global_load_lds(                                                                                \
+                    (const __attribute__((address_space(1))) void *)(gsrc_ + (i_ * 4 + wave) * 256 + lane * 4),                  \
+                    (__attribute__((address_space(3))) void *)(gdst_ + (i_ * 4 + wave) * 256), 16, 0, 0);                        \
+            pp_issued++;                                                                                                         \
+        }                                                                                                                        \
+    } while (0)
+// the head tile's 2 NT k-steps (ED3_HEAD_TILE_MFMAS, rotating weight pieces, counted LDS waits) without LDS-DMA pieces in between
+#define ED3_HEAD_TILE_MFMAS_PP(ACC_)                                                                                             \
+    {                                                                                                                            \
+        const uint32_t wa_ = (uint32_t)(uintptr_t)wb + (uint32_t)lane * 16u;                                                     \
+        u32x4r w2_, w1_, w0_;                                                                                                    \
+        ED3_LDS_READ128(w2_, wa_, 2048); ED3_LDS_READ128(w1_, wa_, 1024); ED3_LDS_READ128(w0_, wa_, 0);                          \
+        _Pragma("unroll") for (int kt = 0; kt < NT; kt++) {                                                                      \
+            _Pragma("unroll") for (int st = 0; st < 2; st++) {                                                                   \
+                const int s1_ = 2 * kt + st + 1;                                                                                 \
+                const bool more_ = s1_ < 2 * NT;                                                                                 \
+                const bf16x8 x0_ = as[kt].p[0][st], x1_ = as[kt].p[1][st], x2_ = as[kt].p[2][st];                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ED3_LGKM_WAIT(2, w2_); ACC_ = ED3_MFU(w2_, x1_, ACC_);                                                           \
+                ED3_LGKM_WAIT(1, w1_); ACC_ = ED3_MFU(w1_, x2_, ACC_); ACC_ = ED3_MFU(w2_, x0_, ACC_);                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) ED3_LDS_READ128(w2_, wa_, ED3_ROT_OFF(kt, st, 2));                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MFU(w1_, x1_, ACC_);                                                                                  \
+                if (more_) { ED3_LGKM_WAIT(1, w0_); } else { ED3_LGKM_WAIT(0, w0_); }                                            \
+                ACC_ = ED3_MFU(w0_, x2_, ACC_); ACC_ = ED3_MFU(w1_, x0_, ACC_);                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) ED3_LDS_READ128(w1_, wa_, ED3_ROT_OFF(kt, st, 1));                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                ACC_ = ED3_MFU(w0_, x1_, ACC_); ACC_ = ED3_MFU(w0_, x0_, ACC_);                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (more_) ED3_LDS_READ128(w0_, wa_, ED3_ROT_OFF(kt, st, 0));                                                    \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    }
+template <int NT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_forward_pp_kernel(DeformDev d)
+{
+    constexpr int NP = 3;
+    constexpr int TS = NP * 512;   // floats per weight tile in the chunk
+    constexpr int PIPE_CHF = ((NT + OTMAX) * TS + 1023) & ~1023;
+    constexpr int PIPE_NI = PIPE_CHF / 1024;
+    extern __shared__ float wl[];
+    constexpr int NBIAS = NHEAD * 32 * NT + NHEAD * OTMAX * 32 + 32 * NT;
+    __shared__ float bias_all[2][NBIAS];   // B2 | B3 | HB of both stages, as frag_layout orders them
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = ED3_FWD_PP_TEAM_BIT == 2 ? (wave8 >> 2) : (wave8 & 1);
+    const int wave = ED3_FWD_PP_TEAM_BIT == 2 ? (wave8 & 3) : (wave8 >> 1);   // the wave's index inside its team
+    const int shw = 3 * d.n_sh;
+    int n_en = 0;
+    for (int k = 0; k < NHEAD; k++) n_en += d.enabled[k] ? 1 : 0;
+    const int n_st = d.use_stage[0] + d.use_stage[1];
+    const int per_iter = n_st * (1 + n_en * NT);
+    // block schedule over PAIRS of 128-Gaussian groups (team t takes group 2 pair + t); tail units are (pair, head)
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    const int my_full = d.full_rounds + ((!d.tail_split && b < d.rem_units) ? 1 : 0);
+    const bool has_tail = d.tail_split && b < d.rem_units * n_en;
+    int tail_k = -1;
+    if (has_tail) { int e = b % n_en; for (int k = 0; k < NHEAD; k++) if (d.enabled[k] && e-- == 0) tail_k = k; }
+    const int tail_pi = d.full_rounds * G + (n_en ? b / n_en : 0);
+    const int pipe_total = my_full * per_iter + (has_tail ? n_st * (1 + NT) : 0);
+    ChunkSeq<NT, false, TS> pipe_seq;
+    pipe_seq.init(d, my_full, tail_k);
+    int pipe_n = 0, pp_issued = 0;
+    for (int s = 0; s < 2; s++)
+        if (d.use_stage[s])
+            for (int e = tid; e < NBIAS; e += 512) bias_all[s][e] = d.frag[s][d.fl.B2 + e];
+    if (team) ED3_PP_ISSUE();   // chunk 0
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (team) { ED3_PP_ISSUE(); ED3_PP_BAR(); }   // team B's leading interval: chunk 1 goes out while team A reads chunk 0
+    for (int it = 0; it < my_full + (has_tail ? 1 : 0); it++) {
+        const int pi = (it < my_full) ? b + it * G : tail_pi;
+        const int bi = 2 * pi + team;
+        const int konly = (it < my_full) ? -1 : tail_k;
+        const int g_raw = bi * 128 + wave * 32 + (lane & 31);
+        const bool gvalid = g_raw < d.P;
+        const int g = gvalid ? g_raw : d.P - 1;
+        float cx[3], cs[3], cr[4], co, csh[24];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { cx[i] = d.xyz[(size_t)g * 3 + i]; cs[i] = d.scales[(size_t)g * 3 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) cr[i] = d.rot[(size_t)g * 4 + i];
+        co = d.opacity[g];
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+            const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (feat < shw) v = load_sh4(d, g, feat, shw);
+            csh[4 * cc] = v.x; csh[4 * cc + 1] = v.y; csh[4 * cc + 2] = v.z; csh[4 * cc + 3] = v.w;
+        }
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            if (d.use_stage[s]) {
+                const float *bias_s = bias_all[s];
+                const float *bias_hb = bias_s + (d.fl.HB - d.fl.B2), *bias_b2 = bias_s, *bias_b3 = bias_s + (d.fl.B3 - d.fl.B2);
+                unsigned long long mka = 0;   // sign mask of a = relu(hid), kept for the data gradient
+                XSplitN<NP> as[NT];
+                {   // ---- trunk: the interval that reads the trunk chunk ----
+                    float eb[1][16];
+                    int gl = g;
+                    ED3_OPAQUE(gl);
+                    load_emb_slots(d.emb, d.E, gl, 0, h, eb[0]);
+                    XSplitN<NP> ebs;
+                    split_tile_n<NP>(eb[0], ebs);
+                    const float *wb = wl + (pipe_n % 3) * PIPE_CHF;
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {   // the first half of the tiles in the first interval, the rest in the second
+                        if (nt == (NT + 1) / 2) { ED3_PP_M_END(); if (team) ED3_PP_ISSUE(); }
+                        f32x4 bv[4];
+                        load_bias4(bv, bias_hb, nt, h);
+                        const f32x16 acc = gemm_tile_bn<NP>(wb + nt * TS, ebs, zero_acc(), lane);
+                        float av[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) av[r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                        if (d.keep && gvalid) store_tile_rows(d.A[s], d.W, g, nt, h, av);
+                        if (d.keep) mka |= (unsigned long long)mask16(av) << (16 * nt);
+                        split_tile_n<NP>(av, as[nt]);
+                    }
+                    if (NT == 1) { ED3_PP_M_END(); if (team) ED3_PP_ISSUE(); }
+                    if (d.keep && gvalid) d.MK[s][((size_t)g) * 2 + h] = mka;
+                    ED3_PP_E_END();
+                }
+                for (int k = 0; k < NHEAD; k++) {
+                    if (!d.enabled[k] || (konly >= 0 && k != konly)) continue;
+                    unsigned long long mkz = 0;   // sign mask of relu(z_k)
+                    const float hc = d.hc[k];
+                    if (k < 4) {
+                        f32x4 yn = {0.f, 0.f, 0.f, 0.f}, yn2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                        for (int nt = 0; nt < NT; nt++) {
+                            // ---- M: the 64 products of the z tile; the lane's 16 W3 values leave the chunk with them ----
+                            const float *wb = wl + (pipe_n % 3) * PIPE_CHF;
+                            f32x4 bv[4];
+                            load_bias4(bv, bias_b2 + k * d.W, nt, h);
+                            f32x16 acc = zero_acc();
+                            ED3_HEAD_TILE_MFMAS_PP(acc)
+                            const float *f3 = wb + NT * TS + 32 * h + (lane & 3);
+                            float w3v[16];
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk++) w3v[kk] = f3[kk * 64];
+                            ED3_PP_M_END();
+                            // ---- E: the chunk after next goes out first (team B), then the epilogue ----
+                            if (team) ED3_PP_ISSUE();
+                            __builtin_amdgcn_sched_barrier(0);
+                            float z[1][16];
+#pragma unroll
+                            for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                            if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int kk = 0; kk < 16; kk += 2) {
+                                yn = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk], z[0][kk], yn, 0, 0, 0);
+                                yn2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w3v[kk + 1], z[0][kk + 1], yn2, 0, 0, 0);
+                            }
+                            ED3_PP_E_END();
+                        }
+                        if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
+                        const float *b3 = bias_b3 + k * OTMAX * 32;
+                        float yo[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const float ys = yn[i] + yn2[i]; yo[i] = (ys + __shfl_xor(ys, 32) + b3[i]) * hc; }  // the two feature halves
+                        if (h == 0) {
+                            if (k == 0) { cx[0] += yo[0]; cx[1] += yo[1]; cx[2] += yo[2]; }
+                            else if (k == 1) { cs[0] += yo[0]; cs[1] += yo[1]; cs[2] += yo[2]; }
+                            else if (k == 2) { cr[0] += yo[0]; cr[1] += yo[1]; cr[2] += yo[2]; cr[3] += yo[3]; }
+                            else co += yo[0];
+                        }
+                    } else {
+                        f32x16 y[OTMAX];
+#pragma unroll
+                        for (int ot = 0; ot < OTMAX; ot++) y[ot] = zero_acc();
+                        const int nout = d.ot[k];
+#pragma unroll 1
+                        for (int nt = 0; nt < NT; nt++) {
+                            // first interval: the 64 products of the z tile; second: its epilogue and the output products
+                            const float *wb = wl + (pipe_n % 3) * PIPE_CHF;
+                            f32x4 bv[4];
+                            load_bias4(bv, bias_b2 + k * d.W, nt, h);
+                            f32x16 acc = zero_acc();
+                            ED3_HEAD_TILE_MFMAS_PP(acc)
+                            ED3_PP_M_END();
+                            if (team) ED3_PP_ISSUE();
+                            __builtin_amdgcn_sched_barrier(0);
+                            float z[1][16];
+#pragma unroll
+                            for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
+                            if (d.keep && gvalid) store_tile_rows(d.ZR[s] + (size_t)k * d.P * d.W, d.W, g, nt, h, z[0]);
+                            if (d.keep) mkz |= (unsigned long long)mask16(z[0]) << (16 * nt);
+                            XSplitN<NP> zs;
+                            split_tile_n<NP>(z[0], zs);
+                            y[0] = gemm_tile_bn<NP>(wb + NT * TS, zs, y[0], lane);   // (W3 of the chunk: still resident, see above)
+                            if (nout > 1) y[1] = gemm_tile_bn<NP>(wb + (NT + 1) * TS, zs, y[1], lane);
+                            ED3_PP_E_END();
+                        }
+                        if (d.keep && gvalid) d.MK[s][((size_t)(1 + k) * d.P + g) * 2 + h] = mkz;
+                        {   // head output bias, after the contraction (see load_bias4)
+                            const float *b3 = bias_b3 + k * OTMAX * 32;
+#pragma unroll
+                            for (int ot = 0; ot < OTMAX; ot++) {
+                                if (ot < nout) {
+                                    f32x4 bv[4];
+                                    load_bias4(bv, b3, ot, h);
+#pragma unroll
+                                    for (int r = 0; r < 16; r++) y[ot][r] += bv[r >> 2][r & 3];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; r++) csh[r] += y[0][r] * hc;
+#pragma unroll
+                        for (int r = 0; r < 8; r++) csh[16 + r] += y[1][r] * hc;
+                    }
+                }
+            }
+            float *const *dst = (s == 0) ? d.sub : d.out;
+            int ge = g;
+            ED3_OPAQUE(ge);
+            if (gvalid && dst[0]) {   // a tail unit owns one head's tensors (a disabled head's pass-through goes with head 0)
+                const bool w0 = konly <= 0, w1 = konly < 0 || konly == 1 || (konly == 0 && !d.enabled[1]);
+                const bool w2 = konly < 0 || konly == 2 || (konly == 0 && !d.enabled[2]);
+                const bool w3 = konly < 0 || konly == 3 || (konly == 0 && !d.enabled[3]);
+                const bool w4 = konly < 0 || konly == 4 || (konly == 0 && !d.enabled[4]);
+                if (h == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        if (w0) dst[0][(size_t)ge * 3 + i] = cx[i];
+                        if (w1) dst[1][(size_t)ge * 3 + i] = cs[i];
+                    }
+                    if (w2) *reinterpret_cast<float4 *>(dst[2] + (size_t)ge * 4) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                    if (w3) dst[3][ge] = co;
+                    if (s == 1 && d.act[0]) {
+                        if (w1) {
+#pragma unroll
+                            for (int i = 0; i < 3; i++) d.act[0][(size_t)ge * 3 + i] = expf(cs[i]);
+                        }
+                        if (w2) *reinterpret_cast<float4 *>(d.act[1] + (size_t)ge * 4) = act_normalize(make_float4(cr[0], cr[1], cr[2], cr[3]));
+                        if (w3) d.act[2][ge] = act_sigmoid(co);
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) {
+                    const int feat = (cc >> 2) * 32 + 8 * (cc & 3) + 4 * h;
+                    if (w4 && feat < shw)
+                        *reinterpret_cast<float4 *>(dst[4] + (size_t)ge * shw + feat) =
+                            make_float4(csh[4 * cc], csh[4 * cc + 1], csh[4 * cc + 2], csh[4 * cc + 3]);
+                }
+            }
+        }
+    }
+    if (!team) ED3_PP_BAR();   // team A's trailing barrier (team B is one interval behind)
+}
+#endif   // ED3_FWD_PP_KERNEL
+
 template <int NT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) deform_dgrad_pipe_kernel(DeformDev d)
 {
@@ -3808,6 +4106,17 @@ static int deform_forward_impl(const ed3dgs_deform_cfg *cfg, const float *table,
                 d.full_rounds = n_bi / G; d.rem_units = n_bi % G;
                 d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G && !opt(OPT_DEFORM_NO_TAIL)) ? 1 : 0;
                 const int np = fwd_pieces(cfg);
+#if ED3_FWD_PP_KERNEL
+                if (np == 3 && opt(OPT_FWD_PINGPONG) && !d.timing) {
+                    // the eight-wave ping-pong form (deform_forward_pp_kernel): one block per CU, schedule over PAIRS of groups
+                    const int n_pair = (n_bi + 1) / 2, G2 = std::min(n_pair, 256);
+                    d.full_rounds = n_pair / G2; d.rem_units = n_pair % G2;
+                    d.tail_split = (d.rem_units > 0 && n_en > 1 && d.rem_units * n_en <= G2 && !opt(OPT_DEFORM_NO_TAIL)) ? 1 : 0;
+                    const size_t lds3 = (size_t)3 * ((((size_t)N + OTMAX) * 1536 + 1023) & ~(size_t)1023) * sizeof(float);   // three chunk buffers
+                    if (!check_hip(hipFuncSetAttribute((const void *)deform_forward_pp_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3), "set LDS size")) return;
+                    hipLaunchKernelGGL((deform_forward_pp_kernel<N>), dim3(G2), dim3(512), lds3, s, d);
+                } else
+#endif
                 if (np == 3) {
                     const size_t lds3 = (size_t)2 * ((((size_t)N + OTMAX) * 1536 + 1023) & ~(size_t)1023) * sizeof(float);   // 1536-float tiles
                     if (!check_hip(hipFuncSetAttribute((const void *)deform_forward_b3_kernel<N, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3), "set LDS size")) return;

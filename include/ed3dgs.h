@@ -244,7 +244,9 @@ enum {
     ED3DGS_PROF_GAUSSIAN_BACKWARD = 8,   /* K8+K9 preprocess_backward_kernel */
     ED3DGS_PROF_SLOTS = 9,
     ED3DGS_PROF_COUNTERS = 16,      /* length of the tile kernels' work-counter array (ed3dgs_profile_tile_counts) */
-    ED3DGS_PROF_COUNT_WORK = 1 << 30   /* flag in the slot mask: also count K7's work (ed3dgs_profile_tile_backward_counts) */
+    ED3DGS_PROF_COUNT_WORK = 1 << 30,  /* flag in the slot mask: also count K7's work (ed3dgs_profile_tile_backward_counts) */
+    ED3DGS_PROF_EVERY_3RD = 1 << 29    /* flag in the slot mask: time every third launch of a slot only (an event pair is two barrier
+                                        * packets, ~12 us of idle stream: bench.py's timed region pays a third of that per step) */
 };
 int ed3dgs_profile_begin_slots(int max_samples, unsigned slot_mask);  /* bit k = time slot k; every event pair costs
                                                                         * stream time, so time few kernels at once */
