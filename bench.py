@@ -452,10 +452,12 @@ def main():
     n_malloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0) if torch.cuda.is_available() else 0
     t0 = time.perf_counter()
     marks[0].record()
+    host_t = [t0]
     for k in range(a.steps):
         step(item_at(k))
         if (k + 1) % MARK_EVERY == 0:
             marks[(k + 1) // MARK_EVERY].record()
+        host_t.append(time.perf_counter())   # when the host had finished enqueueing step k (it waits for K1's count inside it)
     step.drain()
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
@@ -607,10 +609,10 @@ def main():
         kernels["weight-gradient launches together"] = {"avg_launch_ms": tab_avg[4], "launches": tab_n[4]}
     # K7 against the vector-ALU roof: its inner loop issues this many vector instructions per visited iteration (an iteration
     # now differentiates up to four Gaussians, one per quadrant; counted in the ISA of render_backward_kernel<false,true>,
-    # tools/isa.sh, round 3: 64 + 189 at 4 issue cycles, 4 v_exp_f32 + 4 v_rcp_f32 at 8), a SIMD issues one per cycle, 1024 SIMDs
+    # tools/isa.sh, end of round 4: 226 at 4 issue cycles, 4 v_exp_f32 + 4 v_rcp_f32 at 8 -- round 3: 64 + 189 and 8), a SIMD issues one per cycle, 1024 SIMDs
     # at 2.4 GHz; iterations and blended pairs are COUNTED by the kernel in the instrumented pass (popcount of the valid
     # masks), the time is that pass's launch time with the counting on
-    K7_ISSUE_CYCLES_PER_ITER = (64 + 189) * 4 + 8 * 8
+    K7_ISSUE_CYCLES_PER_ITER = 226 * 4 + 8 * 8
     it_per_s = k7_work[0] / (k7_ms * 1e-3) if k7_ms > 0 else 0.0   # counts are per item (deterministic); time = the instrumented pass's launches
     valu_roof = {"visited_iterations_per_launch": k7_work[0], "blended_pairs_per_launch": k7_work[1],
                  "list_entries_staged_per_launch": k7_work[2], "entries_kept_by_tile_reject_per_launch": k7_work[3],
@@ -627,9 +629,10 @@ def main():
     valu_roof["records_added_per_launch"] = k7_work[5]
     valu_roof["record_atomic_bytes_per_launch"] = k7_work[5] * 64
     # K6 against the same roof (ISA of render_forward_kernel<false,true>, tools/isa.sh, round 3: the per-pixel tests of an iteration
-    # -- up to four Gaussians, one per quadrant -- cost 62 four-cycle vector instructions + 4 v_exp_f32, the blend 98 more;
+    # -- up to four Gaussians, one per quadrant -- cost 49 four-cycle vector instructions + 4 v_exp_f32, the blend 76 more (end of round 4;
+    # round 3: 62 + 4 and 98);
     # iterations in which nothing blends pay the tests only and are not counted: a lower bound of the cycles needed)
-    K6_TEST_CYCLES, K6_BLEND_CYCLES = 62 * 4 + 4 * 8, 98 * 4
+    K6_TEST_CYCLES, K6_BLEND_CYCLES = 49 * 4 + 4 * 8, 76 * 4
     k6_cycles = k6_work[0] * (K6_TEST_CYCLES + K6_BLEND_CYCLES)
     valu_roof_k6 = {"visited_iterations_per_launch": k6_work[0], "blended_pairs_per_launch": k6_work[1],
                     "list_entries_staged_per_launch": k6_work[2], "entries_kept_by_tile_reject_per_launch": k6_work[3],
@@ -704,6 +707,9 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "step_ms_windows": [round(x, 4) for x in step_ms],
+        # the HOST's time per step (enqueue + the wait for K1's instance count): a window of the GPU marks far above the median
+        # with a host step of the same size beside it is a host stall (a descheduled thread on a shared box), not a slow kernel
+        "host_ms_per_step": [round((host_t[k + 1] - host_t[k]) * 1e3, 3) for k in range(len(host_t) - 1)],
         "device_mallocs_in_timed_region": n_malloc,   # hipMalloc calls of the caching allocator inside the timed region (each one stalls the stream)
         "step_ms": dict(percentiles(step_ms), source="rank 0, hipEvent marks every %d steps of the timed region on the launch stream; per-step = window / %d" % (MARK_EVERY, MARK_EVERY)),
         "frames_per_s": world * a.steps / dt,
