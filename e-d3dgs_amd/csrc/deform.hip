@@ -1434,11 +1434,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // MEASURED (round 4, same box, three rounds, profiles/r04_fwd_pingpong_ab.md): 0.553 ms against 0.517 ms for the two free-running
 // 4-wave blocks (first version, two buffers and the rgb head / trunk wholly in the first phase: 0.570; teams by bit 0 of the wave
 // index, i.e. both waves of a SIMD in the SAME phase: 0.655 -- so waves w and w + 4 do share a SIMD).  Why it loses: in a strict
-// ping-pong only ONE wave per SIMD issues the 64 dependent 32x32x16 products at a time, and one wave cannot keep the matrix pipe
-// fed (its LDS waits, the s_nop / s_waitcnt between products and the accumulator dependency leave ~1/3 of the slots empty: the
-// probe's one-wave-per-SIMD modes measured 0.58-0.73 of the sustained rate in round 3); two free-running waves fill each other's
-// gaps whenever their product phases overlap, which is most of the time.  A second accumulator per wave would fix the chain, and
-// the kernel has no register left for it.  NOT the default, and not compiled unless -DED3_FWD_PP_KERNEL=1 (tools/ab_build.sh pp
+// ping-pong only ONE wave per SIMD issues a tile's 64 products at a time, and in THIS loop a lone wave does not keep the matrix
+// pipe fed: its operand reads from LDS (three ds_read_b128 per 8 products, issued four products ahead -- one LDS latency) and the
+// waits on them stretch the product phase beyond its 64 x 32 cycles (the probe's one-wave-per-SIMD modes measured 0.58-0.73 of the
+// sustained rate in round 3), the second phase is as long as the first only for the narrow heads, and every wave now passes two
+// barriers per tile instead of one; two free-running waves fill each other's gaps whenever their product phases overlap.  The
+// accumulator chain itself is NOT the problem: tools/ubench/mfma_chain.hip measures one wave per SIMD issuing DEPENDENT
+// 32x32x16 products at the full rate (2.0-2.1 PFLOP/s in a 1-ms launch; two or four independent accumulators change nothing;
+// profiles/r04_mfma_chain_probe.txt).  NOT the default, and not compiled unless -DED3_FWD_PP_KERNEL=1 (tools/ab_build.sh pp
 // -DED3_FWD_PP_KERNEL=1; ED3DGS_FWD_PINGPONG=1 then selects it).
 #ifndef ED3_FWD_PP_KERNEL
 #define ED3_FWD_PP_KERNEL 0
