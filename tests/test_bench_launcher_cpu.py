@@ -93,3 +93,22 @@ def test_workloads_cover_baseline_configs():
     assert W["C4"]["P"] == 200_000 and (W["C4"]["W"], W["C4"]["H"]) == (1100, 1604) and W["C4"]["cams"] * W["C4"]["frames"] == 4500
     assert W["C5"]["P"] == 500_000 and W["C5"]["cams"] * W["C5"]["frames"] == 1200
     assert bench.parse_args([]).workload == "C3" and bench.parse_args([]).gpus == 1
+
+
+def test_stdout_is_the_json_line_only_under_the_drivers_own_torchrun():
+    """The contract is ONE JSON line on stdout.  The driver starts the ranks itself (`python -m torch.distributed.run ... bench.py
+    --gpus N`), so nothing filters what the ranks' libraries print there: gloo announces its connections on stdout, and RCCL prints
+    a five-line version banner on stdout when a rank's first communicator is created (seen on the GPU box in round 4).  bench.py
+    keeps the real stdout aside and points file descriptor 1 at stderr from its first line on."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1",
+                        "--workload", "tiny", "--rehearse-launcher"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), r.stdout      # nothing but rank 0's line
+    d = json.loads(out_lines[0])
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["launched_by_bench"] is False
