@@ -14,6 +14,6 @@ for rep in 1 2 3; do
     timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-modes --steps 40 --warmup 10 2>/dev/null | python -c "
 import json,sys; d=json.load(sys.stdin)
 k=d['kernels']
-print('$b rep $rep: ms/step %.4f median %.4f | fwd %.4f K6 %.4f K7 %.4f | fps %.1f' % (d['ms_per_step'], d['step_ms']['median'], d['roofline']['avg_launch_ms'] if 'avg_launch_ms' in d['roofline'] else -1, d['roofline_tile_forward']['avg_launch_ms'], d['roofline_tile_backward']['avg_launch_ms'], d.get('render_fps') or 0))"
+print('$b rep $rep: ms/step %.4f median %.4f | fwd %.4f K6 %.4f K7 %.4f K8+K9 %.4f | fps %.1f' % (d['ms_per_step'], d['step_ms']['median'], d['roofline']['avg_launch_ms'] if 'avg_launch_ms' in d['roofline'] else -1, d['roofline_tile_forward']['avg_launch_ms'], d['roofline_tile_backward']['avg_launch_ms'], k['preprocess_backward_kernel (K8+K9)']['avg_launch_ms'], d.get('render_fps') or 0))"
   done
 done
