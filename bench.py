@@ -81,14 +81,17 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
     def step(item, backward=True, coord=False):
         ci, fi = D.item_of(item, wl["cams"], F)
         cam = cams[ci].with_time(fi / F)
+        t_a = time.perf_counter()
         pkg = render(cam, model, PIPE, bg, kernel_size=0.0, require_coord=coord, require_depth=True, cam_no=None,
                      iter=20000, num_down_emb_c=30, num_down_emb_f=30, disable_filter3D=True)
+        t_b = time.perf_counter()
         if not backward:
             return pkg, None
         # fixed upstream gradients stand in for the L1/SSIM + depth-normal losses (the losses are outside the
         # path): they enter the backward directly
         outs = [pkg["render"], pkg["expected_depth"], pkg["median_depth"], pkg["normal"]]
         torch.autograd.backward(outs, ups)
+        step.host_split.append((t_b - t_a, time.perf_counter() - t_b))   # host seconds in render() (it waits for K1's count) / in backward()
         # logging stand-in (train.py logs the image loss and PSNR): <image, its upstream gradient> and a PSNR against mid-grey,
         # one fused launch (csrc/stats.hip; ten torch launches, 90 us, as separate ops) into one of two alternating buffers
         # (the previous step's vector may still be in its all-reduce)
@@ -119,6 +122,7 @@ def make_step(model, cams, grads, wl, device, dp_grads=False):
             inflight.pop().wait()
 
     step.drain = drain
+    step.host_split = []
     step.n = 0
     step.probe = None
     return step
@@ -452,6 +456,7 @@ def main():
     n_malloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0) if torch.cuda.is_available() else 0
     t0 = time.perf_counter()
     marks[0].record()
+    step.host_split.clear()
     host_t = [t0]
     for k in range(a.steps):
         step(item_at(k))
@@ -710,6 +715,7 @@ def main():
         # the HOST's time per step (enqueue + the wait for K1's instance count): a window of the GPU marks far above the median
         # with a host step of the same size beside it is a host stall (a descheduled thread on a shared box), not a slow kernel
         "host_ms_per_step": [round((host_t[k + 1] - host_t[k]) * 1e3, 3) for k in range(len(host_t) - 1)],
+        "host_ms_in_render_and_backward": [[round(a_ * 1e3, 3), round(b_ * 1e3, 3)] for a_, b_ in step.host_split[:a.steps]],
         "device_mallocs_in_timed_region": n_malloc,   # hipMalloc calls of the caching allocator inside the timed region (each one stalls the stream)
         "step_ms": dict(percentiles(step_ms), source="rank 0, hipEvent marks every %d steps of the timed region on the launch stream; per-step = window / %d" % (MARK_EVERY, MARK_EVERY)),
         "frames_per_s": world * a.steps / dt,
