@@ -127,3 +127,26 @@ def test_cfg_args_is_parsed_without_eval(tmp_path):
         (tmp_path / "cfg_args").write_text(bad)
         with pytest.raises(ValueError):
             read_cfg_args(str(tmp_path))
+
+
+def test_ply_bytes_equal_what_the_references_save_ply_hands_to_plyfile(tmp_path):
+    """tests/golden/ply_reference.npz (tools/gen_densify_golden.py): the REFERENCE's own save_ply (scene/gaussian_model.py:261-283) run on
+    a 37-Gaussian model with capturing stand-ins for plyfile's classes -- the attribute names in construct_list_of_attributes order and
+    the structured vertex array's bytes (what plyfile writes behind the header for an all-f4 binary_little_endian element).
+    SynthGaussianModel.save_ply must produce the same property list and the same body, byte for byte."""
+    from ed3dgs_amd import synthetic as S
+    from ed3dgs_amd.model import SynthGaussianModel
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ply_reference.npz"))
+    scene = S.make_scene(37, seed=9)
+    for k, attr in (("xyz", "xyz"), ("f_dc", "f_dc"), ("f_rest", "f_rest"), ("opacity", "opacity"), ("log_scale", "log_scale"),
+                    ("rot", "rot"), ("embedding", "embedding")):
+        np.testing.assert_array_equal(getattr(scene, attr).numpy(), z[k])        # same synthetic model as the generator's
+    scene.tongue_class = torch.from_numpy(z["tongue_class"])
+    scene.filter_3D = torch.from_numpy(z["filter_3D"])
+    m = SynthGaussianModel(scene, device="cpu")
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    m.save_ply(path)
+    head, _, body = open(path, "rb").read().partition(b"end_header\n")
+    lines = head.decode("ascii").strip().split("\n")
+    assert lines[3:] == ["property float %s" % n for n in z["names"].tolist()]
+    assert body == z["vertex_bytes"].tobytes()

@@ -101,5 +101,49 @@ def main():
     print("wrote densify_reference.npz: %d -> %d Gaussians" % (n0, n1))
 
 
+def ply_golden(gm):
+    """tests/golden/ply_reference.npz: the reference's own `save_ply` (scene/gaussian_model.py:261-283) run on a 37-Gaussian model with
+    stand-ins for plyfile's two classes that CAPTURE the structured array it hands them (plyfile itself is not installed; for an
+    all-`f4` vertex element `binary_little_endian` plyfile writes exactly that array's bytes behind the header): attribute names in
+    `construct_list_of_attributes` order (:231-248) + the vertex bytes.  ed3dgs_amd.model.save_ply must write the same names and bytes."""
+    import tempfile
+    from ed3dgs_amd import synthetic as S
+    captured = {}
+
+    class _Element:
+        @staticmethod
+        def describe(elements, name):
+            captured["elements"], captured["name"] = elements, name
+            return "element"
+
+    class _Data:
+        def __init__(self, els):
+            pass
+
+        def write(self, path):
+            captured["path"] = path
+    gm.PlyElement, gm.PlyData = _Element, _Data
+    Pn = 37
+    sc = S.make_scene(Pn, seed=9)
+    g = torch.Generator().manual_seed(10)
+    m = gm.GaussianModel.__new__(gm.GaussianModel)
+    m._xyz, m._features_dc, m._features_rest = sc.xyz, sc.f_dc, sc.f_rest
+    m._opacity, m._scaling, m._rotation, m._embedding = sc.opacity, sc.log_scale, sc.rot, sc.embedding
+    m.tongue_class = (torch.rand(Pn, 1, generator=g) > 0.5).float()
+    m.filter_3D = torch.rand(Pn, 1, generator=g) * 0.01
+    with tempfile.TemporaryDirectory() as td:
+        m.save_ply(os.path.join(td, "point_cloud", "iteration_7", "point_cloud.ply"))
+    el = captured["elements"]
+    assert captured["name"] == "vertex" and el.shape == (Pn,)
+    names = list(el.dtype.names)
+    assert names == m.construct_list_of_attributes() and all(el.dtype[n] == np.dtype("f4") for n in names)
+    np.savez_compressed(os.path.join(OUT, "ply_reference.npz"), names=np.array(names), vertex_bytes=np.frombuffer(el.tobytes(), dtype=np.uint8),
+                        xyz=sc.xyz.numpy(), f_dc=sc.f_dc.numpy(), f_rest=sc.f_rest.numpy(), opacity=sc.opacity.numpy(),
+                        log_scale=sc.log_scale.numpy(), rot=sc.rot.numpy(), embedding=sc.embedding.numpy(),
+                        tongue_class=m.tongue_class.numpy(), filter_3D=m.filter_3D.numpy())
+    print("wrote ply_reference.npz: %d properties, %d vertex bytes" % (len(names), el.nbytes))
+
+
 if __name__ == "__main__":
     main()
+    ply_golden(sys.modules["scene.gaussian_model"])
