@@ -71,6 +71,12 @@ def make_rasterizer_package(log):
             planes = [torch.full((3, H, W), 101.0), radii, torch.full((3, H, W), 102.0), torch.full((3, H, W), 103.0), torch.full((1, H, W), 104.0),
                       torch.full((1, H, W), 105.0), torch.full((1, H, W), 106.0), torch.full((1, H, W), 107.0), torch.full((3, H, W), 108.0)]
             return tuple(planes)   # color, radii, coord, mcoord, depth, mdepth, alpha, tongue, normal
+
+        def integrate(self, **kw):
+            log["integrate_kwargs"] = {k: describe(v) for k, v in kw.items()}
+            radii = torch.tensor([3, 0, 5, 0, 9], dtype=torch.int32)
+            return (torch.full((9, H, W), 201.0), torch.full((7,), 202.0), torch.full((7, 3), 203.0), torch.full((7, 2), 204.0),
+                    torch.full((7,), 205.0), radii)   # color, alpha_integrated, color_integrated, point_coordinate, point_sdf, radii
     mod = types.ModuleType("diff_gaussian_rasterization")
     mod.GaussianRasterizationSettings, mod.GaussianRasterizer = Settings, GaussianRasterizer
     return mod
@@ -128,7 +134,7 @@ class Pipe:
 
 CASES = [("render", dict()), ("render", dict(disable_filter3D=False, scaling_modifier=0.7, require_coord=False)),
          ("render", dict(override_color=torch.full((P, 3), 40.0))), ("render_tongue", dict()), ("render_without_tongue", dict()),
-         ("render_tongue", dict(disable_filter3D=False))]
+         ("render_tongue", dict(disable_filter3D=False)), ("integrate", dict()), ("integrate", dict(scaling_modifier=0.7))]
 
 
 def probe(module, install):
@@ -138,8 +144,12 @@ def probe(module, install):
         log = {}
         install(make_rasterizer_package(log))
         model = FakeModel(log)
-        res = getattr(module, fn)(FakeCamera(), model, Pipe(), torch.full((3,), 50.0), 0.3, cam_no=2, iter=1234, num_down_emb_c=7,
-                                  num_down_emb_f=8, **kw)
+        if fn == "integrate":   # gaussian_renderer.integrate (:551-661): the mesh-extraction probe's glue
+            res = module.integrate(torch.full((7, 3), 60.0), FakeCamera(), model, Pipe(), torch.full((3,), 50.0), 0.3, 4321,
+                                   num_down_emb_c=7, num_down_emb_f=8, **kw)
+        else:
+            res = getattr(module, fn)(FakeCamera(), model, Pipe(), torch.full((3,), 50.0), 0.3, cam_no=2, iter=1234, num_down_emb_c=7,
+                                      num_down_emb_f=8, **kw)
         log["result"] = {k: describe(v) for k, v in res.items()}
         out.append({"function": fn, "kwargs": sorted(kw), **log})
     return out

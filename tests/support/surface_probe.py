@@ -110,6 +110,14 @@ def probe(pkg, install):
     ras = pkg.GaussianRasterizer(raster_settings=settings_of(pkg))
     vis = ras.markVisible(torch.full((P, 3), 30.0))
     result["mark_visible"] = {"calls": log, "returned": describe(vis)}
+    # GaussianRasterizer.integrate (:245-312): 23 positional arguments to _C.integrate_gaussians_to_points, ten results back, six returned
+    log = []
+    install(make_recorder(log, {}))
+    ras = pkg.GaussianRasterizer(raster_settings=settings_of(pkg))
+    t = {k: torch.full(IN_SHAPES[k], IN_TAGS[k]) for k in IN_SHAPES}
+    outs = ras.integrate(points3D=t["points3D"], means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], shs=t["sh"],
+                         scales=t["scales"], rotations=t["rotations"])
+    result["integrate"] = {"calls": log, "returned": [describe(o) for o in outs]}
     for bad in (dict(), dict(shs=1, colors_precomp=1, scales=1, rotations=1), dict(shs=1), dict(shs=1, scales=1, rotations=1, cov3D_precomp=1)):
         try:
             ras(means3D=None, means2D=None, opacities=None, tongue_class=None, **bad)

@@ -32,12 +32,16 @@ def _ours():
 def test_render_glue_does_what_the_references_does():
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "render_glue_reference.json")))
     got = json.loads(json.dumps(_ours()))
-    assert [(c["function"], c["kwargs"]) for c in got] == [(c["function"], c["kwargs"]) for c in ref] and len(ref) == 6
+    assert [(c["function"], c["kwargs"]) for c in got] == [(c["function"], c["kwargs"]) for c in ref] and len(ref) == 8
     for r, g in zip(ref, got):
         tag = (r["function"], r["kwargs"])
         assert g["settings"] == r["settings"], tag
         assert g["deformation_args"] == r["deformation_args"], tag           # (the time as its value: tensor there, number here)
         assert g["deformation_kwargs"] == r["deformation_kwargs"], tag       # iter, num_down_emb_c, num_down_emb_f
+        if r["function"] == "integrate":   # rasterizer.integrate's keywords: filtered scales + opacity, activated rotations, SH as they come
+            assert g["integrate_kwargs"] == r["integrate_kwargs"], tag
+            assert g["result"] == r["result"], tag
+            continue
         rk, gk = dict(r["rasterizer_kwargs"]), dict(g["rasterizer_kwargs"])
         if "override_color" in r["kwargs"]:
             assert rk["shs"] is not None and rk["colors_precomp"] is not None   # the reference hands over both (and its rasterizer raises)

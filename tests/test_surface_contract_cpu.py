@@ -42,4 +42,12 @@ def test_the_python_surface_hands_C_what_the_references_does():
         assert g["input_grads"] == r["input_grads"], variant      # which _C gradient lands where; tongue_class gets none
     assert len(ref["sh_scales_rotations"]["calls"][0][1]) == 23 and len(ref["sh_scales_rotations"]["calls"][1][1]) == 32
     assert got["mark_visible"] == ref["mark_visible"]
+    # _C.integrate_gaussians_to_points: 23 positional arguments.  One documented difference: argument 15, `subpixel_offset`, is a
+    # freshly filled (H, W, 2) zero tensor in the reference (:274) and None here -- neither native side reads it
+    # (DGR/rasterize_points.cu / diff_gaussian_rasterization/_C.py: accepted and ignored), so this surface does not fill 8 H W bytes per call
+    rc, gc = ref["integrate"]["calls"][0], got["integrate"]["calls"][0]
+    assert rc[0] == gc[0] == "integrate_gaussians_to_points" and len(rc[1]) == len(gc[1]) == 23
+    assert rc[1][15] == ["tensor", 0.0, [4, 6, 2]] and gc[1][15] == ["NoneType", "None"]
+    assert [a for i, a in enumerate(gc[1]) if i != 15] == [a for i, a in enumerate(rc[1]) if i != 15]
+    assert got["integrate"]["returned"] == ref["integrate"]["returned"]
     assert got["argument_errors"] == ref["argument_errors"]

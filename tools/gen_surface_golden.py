@@ -27,6 +27,9 @@ def main():
     pkg = importlib.util.module_from_spec(spec)
     sys.modules["ref_dgr"] = pkg
     spec.loader.exec_module(pkg)          # `from . import _C` binds the holder registered above
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_raster_golden as G
+    pkg.torch = G._TorchCpu()             # integrate() builds its sub-pixel offsets with device="cuda" (:274)
 
     def install(rec):
         pkg._C = rec
