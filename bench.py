@@ -337,7 +337,9 @@ def main():
 
     def emit(obj):
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+        data = (json.dumps(obj) + "\n").encode()
+        while data:                                   # (a pipe may take the ~12 KB line in pieces)
+            data = data[os.write(real_stdout, data):]
 
     from ed3dgs_amd import dist as D
     if a.rehearse_launcher:
