@@ -1074,6 +1074,9 @@ __device__ __forceinline__ f32x16 gemm_tile_bn(const float *wl, const XSplitN<NP
 // weights runs under the wave's own MFMAs with no extra registers.  The plain form (gemm_tile_bn) reads a step's three pieces
 // together and waits lgkmcnt(0) in front of its first MFMA: ~150 cycles per k-step in which only the SIMD's other wave can keep
 // the matrix pipe busy.  -DED3_FWD_ROT=0 builds the plain form (A/B).
+// ED3_FWD_ROT == 3 (narrow heads only; the rgb head keeps 2): the three pieces of a WHOLE k-step requested one step (8 products, 256
+// cycles) ahead into a second register set, the tile's bias loads moved behind the products to make room.  Measured in round 4
+// (same box, three rounds): forward 0.5253 -> 0.5326 ms -- the weight reads are already covered at four products of lead; NOT kept.
 #ifndef ED3_FWD_ROT
 #define ED3_FWD_ROT 2
 #endif
@@ -1107,8 +1110,40 @@ typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 #define ED3_LGKM_WAIT(N_, REG_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(REG_))
 #define ED3_MF(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
 #define ED3_MFU(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), B_, C_, 0, 0, 0)
-#define ED3_HEAD_TILE_MFMAS(ACC_)                                                                                                \
-    if constexpr (NP == 3 && ED3_FWD_ROT == 2 && ED3_NP3_SMAX == 3) {                                                             \
+#define ED3_HEAD_TILE_MFMAS_R(ACC_, ROT_)                                                                                        \
+    if constexpr (NP == 3 && (ROT_) == 3 && ED3_NP3_SMAX == 3) {                                                                  \
+        /* two register sets: step s + 1's three pieces are requested at the START of step s (a whole step = 8 products = 256 \
+           cycles ahead) and awaited with lgkmcnt(3) -- the three just issued may still be in flight, everything older has landed */ \
+        const uint32_t wa_ = (uint32_t)(uintptr_t)wb + (uint32_t)lane * 16u;                                                     \
+        u32x4r wA_[3], wB_[3];                                                                                                   \
+        ED3_LDS_READ128(wA_[2], wa_, 2048); ED3_LDS_READ128(wA_[1], wa_, 1024); ED3_LDS_READ128(wA_[0], wa_, 0);                 \
+        _Pragma("unroll") for (int kt = 0; kt < NT; kt++) {                                                                      \
+            _Pragma("unroll") for (int st = 0; st < 2; st++) {                                                                   \
+                const int s1_ = 2 * kt + st + 1;                                                                                 \
+                const bool more_ = s1_ < 2 * NT;                                                                                 \
+                const bool even_ = ((2 * kt + st) & 1) == 0;                                                                     \
+                const bf16x8 x0_ = as[kt].p[0][st], x1_ = as[kt].p[1][st], x2_ = as[kt].p[2][st];                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                if (even_) {                                                                                                     \
+                    if (more_) { ED3_LDS_READ128(wB_[2], wa_, ED3_ROT_OFF(kt, st, 2)); ED3_LDS_READ128(wB_[1], wa_, ED3_ROT_OFF(kt, st, 1)); ED3_LDS_READ128(wB_[0], wa_, ED3_ROT_OFF(kt, st, 0)); \
+                                 asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wA_[0]), "+v"(wA_[1]), "+v"(wA_[2])); }                \
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wA_[0]), "+v"(wA_[1]), "+v"(wA_[2]));                        \
+                    ACC_ = ED3_MFU(wA_[2], x1_, ACC_); ACC_ = ED3_MFU(wA_[1], x2_, ACC_); ACC_ = ED3_MFU(wA_[2], x0_, ACC_);     \
+                    ACC_ = ED3_MFU(wA_[1], x1_, ACC_); ACC_ = ED3_MFU(wA_[0], x2_, ACC_); ACC_ = ED3_MFU(wA_[1], x0_, ACC_);     \
+                    ACC_ = ED3_MFU(wA_[0], x1_, ACC_); ACC_ = ED3_MFU(wA_[0], x0_, ACC_);                                        \
+                } else {                                                                                                         \
+                    if (more_) { ED3_LDS_READ128(wA_[2], wa_, ED3_ROT_OFF(kt, st, 2)); ED3_LDS_READ128(wA_[1], wa_, ED3_ROT_OFF(kt, st, 1)); ED3_LDS_READ128(wA_[0], wa_, ED3_ROT_OFF(kt, st, 0)); \
+                                 asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wB_[0]), "+v"(wB_[1]), "+v"(wB_[2])); }                \
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wB_[0]), "+v"(wB_[1]), "+v"(wB_[2]));                        \
+                    ACC_ = ED3_MFU(wB_[2], x1_, ACC_); ACC_ = ED3_MFU(wB_[1], x2_, ACC_); ACC_ = ED3_MFU(wB_[2], x0_, ACC_);     \
+                    ACC_ = ED3_MFU(wB_[1], x1_, ACC_); ACC_ = ED3_MFU(wB_[0], x2_, ACC_); ACC_ = ED3_MFU(wB_[1], x0_, ACC_);     \
+                    ACC_ = ED3_MFU(wB_[0], x1_, ACC_); ACC_ = ED3_MFU(wB_[0], x0_, ACC_);                                        \
+                }                                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+            }                                                                                                                    \
+            GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                                               \
+        }                                                                                                                        \
+    } else if constexpr (NP == 3 && (ROT_) >= 2 && ED3_NP3_SMAX == 3) {                                                            \
         const uint32_t wa_ = (uint32_t)(uintptr_t)wb + (uint32_t)lane * 16u;   /* LDS byte address of this lane's fragment */     \
         u32x4r w2_, w1_, w0_;                                                                                                    \
         ED3_LDS_READ128(w2_, wa_, 2048); ED3_LDS_READ128(w1_, wa_, 1024); ED3_LDS_READ128(w0_, wa_, 0);                          \
@@ -1142,7 +1177,7 @@ typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
             }                                                                                                                    \
             if (!ED3_FWD_PIECE_SPREAD) GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                    \
         }                                                                                                                        \
-    } else if constexpr (NP == 3 && ED3_FWD_ROT == 1 && ED3_NP3_SMAX == 3) {                                                      \
+    } else if constexpr (NP == 3 && (ROT_) == 1 && ED3_NP3_SMAX == 3) {                                                            \
         const bf16x8 *wq_ = reinterpret_cast<const bf16x8 *>(wb) + lane;                                                         \
         bf16x8 w2_ = wq_[2 * 64], w1_ = wq_[1 * 64], w0_ = wq_[0];                                                               \
         _Pragma("unroll") for (int kt = 0; kt < NT; kt++) {                                                                      \
@@ -1171,6 +1206,8 @@ typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
             GPIPE_PIECES(kt * ((PIPE_NI + NT - 1) / NT), (PIPE_NI + NT - 1) / NT);                                               \
         }                                                                                                                        \
     }
+#define ED3_HEAD_TILE_MFMAS(ACC_) ED3_HEAD_TILE_MFMAS_R(ACC_, ED3_FWD_ROT)                    /* narrow heads */
+#define ED3_HEAD_TILE_MFMAS_WIDE(ACC_) ED3_HEAD_TILE_MFMAS_R(ACC_, (ED3_FWD_ROT == 3 ? 2 : ED3_FWD_ROT))   /* rgb head: no room for the second set */
 // byte offset of piece Q_ of the k-step AFTER (kt, st): an "n" (immediate) operand, so it has to be a constant expression of the
 // unrolled loop indices -- the switch below spells the 2 NT <= 8 cases out
 #define ED3_ROT_OFF(KT_, ST_, Q_) ((3 * (2 * (KT_) + (ST_) + 1) + (Q_)) * 1024)
@@ -1282,10 +1319,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             if (timed) { tlast = clock64(); ntile++; }
                             const float *wb = PIPE_CUR();
                             f32x4 bv[4];
-                            load_bias4(bv, bias_b2 + k * d.W, nt, h);
+                            if (ED3_FWD_ROT != 3) load_bias4(bv, bias_b2 + k * d.W, nt, h);
                             f32x16 acc = zero_acc();
                             GPIPE_SPREAD_BEGIN()
                             ED3_HEAD_TILE_MFMAS(acc)
+                            if (ED3_FWD_ROT == 3) load_bias4(bv, bias_b2 + k * d.W, nt, h);   // (from LDS, with the W3 values below: 16 registers free during the products)
                             FW_MARK(0);
                             // the 16 W3 values of this lane are fetched from LDS in one go, ahead of the epilogue's VALU
                             // work: read-wait-MFMA per k-slot (what the compiler emits for the plain loop) is a chain of
@@ -1335,7 +1373,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                             load_bias4(bv, bias_b2 + k * d.W, nt, h);
                             f32x16 acc = zero_acc();
                             GPIPE_SPREAD_BEGIN()
-                            ED3_HEAD_TILE_MFMAS(acc)
+                            ED3_HEAD_TILE_MFMAS_WIDE(acc)
                             float z[1][16];
 #pragma unroll
                             for (int r = 0; r < 16; r++) z[0][r] = fmaxf(acc[r] + bv[r >> 2][r & 3], 0.f);
